@@ -1,0 +1,153 @@
+"""CPU restatement of the caller-side harness around the sampling loop, and of the frozen
+stage-1 decode that follows it (the "decoded-coordinate" half of the parity metric).
+
+Test infrastructure only (see ``oracle/__init__.py``).
+
+Reference lines restated (under /root/reference/src/):
+  models/composites/lightning_base.py:240-263   setup_conditioning (cannot be imported here: needs lightning)
+  models/composites/lightning_base.py:217-238   sample(): noise -> sample_fn(...)[-1] -> decode
+  models/composites/lightning_base.py:28-31,42-44  post_quant (LayerNorm without affine, then Linear) + decoder
+  models/components/decoder.py:12-102           Decoder: queries -> self-attn blocks -> cross blocks -> output block -> heads
+  modules/torch_modules.py:104-147              PreNorm / FeedForward
+  modules/torch_modules.py:150-264              Attention / SelfAttention / blocks (SDPA, optional QK RMS norm)
+  modules/entity_embeddings.py:7-33             entity embedding with max_norm (renormalised rows)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import latent_net, transport
+
+
+def setup_conditioning(latents: Tensor, cond_idx: Tuple[int, int], mask_cond_mean: bool) -> Tuple[Tensor, Tensor]:
+    B, T, L, _ = latents.shape
+    mask = torch.zeros(B, T, L, dtype=torch.int64)
+    mask[:, cond_idx[0]: cond_idx[1]] = 1
+    keep = mask.unsqueeze(-1).bool()
+    if mask_cond_mean:
+        fill = latents[:, cond_idx[0]: cond_idx[1]].mean(dim=1).unsqueeze(1)
+        x_cond = torch.where(keep, latents, fill)
+    else:
+        x_cond = torch.where(keep, latents, torch.zeros((), dtype=latents.dtype))
+    return x_cond, mask
+
+
+def sample_latents(params, shape: latent_net.NetShape, tr: transport.Transport, init: Tensor, x_cond: Tensor,
+                   x_cond_mask: Tensor, y: Optional[Tensor] = None, sampling_method="ODE", sampling_kwargs=None,
+                   **extra) -> Tensor:
+    """Counterpart of the sample_fn call in lightning_base.py:230-234; returns the final latents."""
+    fn = transport.get_sample_fn(tr, sampling_method, sampling_kwargs, **extra)
+
+    def model(xt, t, **kw):
+        return latent_net.forward(params, shape, xt, t.to(xt.dtype), **kw)
+
+    kw = {"x_cond": x_cond, "x_cond_mask": x_cond_mask}
+    if y is not None:
+        kw["y"] = y
+    with torch.no_grad():
+        return fn(init, model, **kw)[-1]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# frozen stage-1 decoder
+
+
+@dataclass(frozen=True)
+class DecoderShape:
+    dim_latent: int = 32
+    dim_query: int = 128
+    dim_head_cross: int = 16
+    dim_head_latent: int = 16
+    num_head_cross: int = 8
+    num_head_latent: int = 2
+    num_block_cross: int = 0
+    num_block_attn: int = 1
+    qk_norm: bool = True
+    n_entities: int = 32
+    out_pos: int = 3
+    act: str = "gelu_erf"  # md17 first-stage config uses src.modules.torch_modules.GELU (exact erf)
+
+
+def _ln(x, w=None, b=None, eps=1e-5):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def _act(x, kind):
+    if kind == "gelu_erf":
+        return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    return torch.nn.functional.gelu(x, approximate="tanh")
+
+
+def _rms(x, scale):
+    xf = x.float()
+    r = torch.rsqrt(torch.mean(xf * xf, dim=-1, keepdim=True) + 1e-6)
+    return (xf * r).to(x.dtype) * scale
+
+
+def _heads(t, h):
+    b, n, hd = t.shape
+    return t.reshape(b, n, h, hd // h).permute(0, 2, 1, 3)
+
+
+def _mha(p, pre, xq, ctx, heads, dim_head, qk_norm, fused_qkv):
+    if fused_qkv:
+        q, k, v = torch.nn.functional.linear(xq, p[pre + ".to_qkv.weight"]).chunk(3, dim=-1)
+    else:
+        q = torch.nn.functional.linear(xq, p[pre + ".to_q.weight"])
+        k, v = torch.nn.functional.linear(ctx, p[pre + ".to_kv.weight"]).chunk(2, dim=-1)
+    q, k, v = _heads(q, heads), _heads(k, heads), _heads(v, heads)
+    if qk_norm:
+        q = _rms(q, p[pre + ".norm.query_norm.scale"]).to(v.dtype)
+        k = _rms(k, p[pre + ".norm.key_norm.scale"]).to(v.dtype)
+    s = torch.matmul(q, k.transpose(-1, -2)) * dim_head ** -0.5
+    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    o = o.permute(0, 2, 1, 3).reshape(xq.shape[0], xq.shape[1], heads * dim_head)
+    return torch.nn.functional.linear(o, p[pre + ".to_out.weight"], p[pre + ".to_out.bias"])
+
+
+def _ff(p, pre, x, act):
+    x = _ln(x, p[pre + ".norm.weight"], p[pre + ".norm.bias"])
+    x = _act(torch.nn.functional.linear(x, p[pre + ".fn.net.0.0.weight"], p[pre + ".fn.net.0.0.bias"]), act)
+    return torch.nn.functional.linear(x, p[pre + ".fn.net.1.weight"], p[pre + ".fn.net.1.bias"])
+
+
+def _self_block(p, pre, x, ds: DecoderShape):
+    xn = _ln(x, p[pre + ".attn.norm.weight"], p[pre + ".attn.norm.bias"])
+    x = _mha(p, pre + ".attn.fn", xn, xn, ds.num_head_latent, ds.dim_head_latent, ds.qk_norm, True) + x
+    return _ff(p, pre + ".ff", x, ds.act) + x
+
+
+def _cross_block(p, pre, x, ctx, heads, dim_head, ds: DecoderShape):
+    xn = _ln(x, p[pre + ".attn.norm.weight"], p[pre + ".attn.norm.bias"])
+    cn = _ln(ctx, p[pre + ".attn.norm_context.weight"], p[pre + ".attn.norm_context.bias"])
+    x = _mha(p, pre + ".attn.fn", xn, cn, heads, dim_head, ds.qk_norm, False) + x
+    return _ff(p, pre + ".ff", x, ds.act) + x
+
+
+def decode(p: Dict[str, Tensor], ds: DecoderShape, z: Tensor, entities: Tensor) -> Tensor:
+    """z: [F, L, dim_latent] final latents of F frames; entities: [F, A] int -> positions [F, A, out_pos].
+
+    Parameter names: ``post_quant.1.*`` (lightning_base.py:28-31) and ``decoder.*`` (decoder.py:31-80).
+    The entity table is used with rows clipped to unit norm, which is what nn.Embedding(max_norm=1)
+    does to the looked-up rows at forward time (entity_embeddings.py:25)."""
+    lat = torch.nn.functional.linear(_ln(z), p["post_quant.1.weight"], p["post_quant.1.bias"])
+    table = p["decoder.entity_embedding.embedding.weight"]
+    norms = table.norm(dim=-1, keepdim=True)
+    table = torch.where(norms > 1.0, table / (norms + 1e-7), table)  # torch's embedding_renorm_ formula
+    q = torch.nn.functional.linear(table[entities], p["decoder.query_mlp.1.weight"], p["decoder.query_mlp.1.bias"])
+    for i in range(ds.num_block_attn):
+        lat = _self_block(p, f"decoder.self_attn_blocks.{i}", lat, ds)
+    for i in range(ds.num_block_cross):
+        lat = _cross_block(p, f"decoder.cross_attn_blocks.{i}", lat, q, ds.num_head_cross, ds.dim_head_cross, ds)
+    o = _cross_block(p, "decoder.output_block", q, lat, ds.num_head_cross, ds.dim_head_cross, ds)
+    o = _act(torch.nn.functional.linear(o, p["decoder.output_layers.pos.0.weight"], p["decoder.output_layers.pos.0.bias"]), ds.act)
+    return torch.nn.functional.linear(o, p["decoder.output_layers.pos.2.weight"], p["decoder.output_layers.pos.2.bias"])
+
+
+def rel_l2(a: Tensor, b: Tensor) -> float:
+    return float((a.double() - b.double()).norm() / b.double().norm())

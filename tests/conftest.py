@@ -1,0 +1,62 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Fixture:
+    """npz fixture with 'group/key' names exposed as nested dicts of torch tensors."""
+
+    def __init__(self, name):
+        self.raw = np.load(os.path.join(GOLDEN, name))
+
+    def group(self, prefix):
+        out = {}
+        for k in self.raw.files:
+            if k.startswith(prefix + "/"):
+                out[k[len(prefix) + 1:]] = torch.from_numpy(self.raw[k])
+        return out
+
+    def __getitem__(self, k):
+        return torch.from_numpy(np.asarray(self.raw[k]))
+
+    def has(self, k):
+        return k in self.raw.files
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = Fixture(name)
+        return cache[name]
+
+    return load
+
+
+def shape_from(d):
+    from oracle.latent_net import NetShape
+    g = lambda k: d[k].item() if hasattr(d[k], "item") else d[k]  # noqa: E731
+    v = int(g("vec_in_dim"))
+    mr = float(g("mlp_ratio"))
+    return NetShape(depth=int(g("depth")), in_dim=int(g("in_dim")), hidden_size=int(g("hidden_size")),
+                    num_heads=int(g("num_heads")), mlp_ratio=int(mr) if mr == int(mr) else mr,
+                    vec_in_dim=None if v < 0 else v, theta=int(g("theta")), normalize=bool(g("normalize")),
+                    share_weights=bool(g("share_weights")))
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))

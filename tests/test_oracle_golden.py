@@ -1,0 +1,124 @@
+"""CPU: the oracle restatement against the golden vectors produced by the reference's own modules
+(tools/make_fixtures.py).  Tolerances: 2e-6 relative L2 for one fp32 network evaluation, 5e-5 for
+multi-step samplers (late steps amplify fp32 rounding by (pi/2)/cos(pi t/2)), exact for integers."""
+import torch
+
+from conftest import rel_l2, shape_from
+from oracle import harness, latent_net, transport as otr
+
+
+def test_f1_block_intermediates(golden):
+    f = golden("f1_block.npz")
+    sh = shape_from(f.group("shape"))
+    p = f.group("p")
+    taps = {}
+    out = latent_net.forward(p, sh, f["x"], f["t"], f["x_cond"], f["mask"], f["y"], taps=taps)
+    ref = f.group("taps")
+    assert len(ref) == 35
+    for k, v in ref.items():
+        assert rel_l2(taps[k].reshape(v.shape), v) < 2e-6, k
+    assert rel_l2(out, ref["out"]) < 2e-6
+    p64 = latent_net.cast_params(p, torch.float64)
+    out64 = latent_net.forward(p64, sh, f["x"].double(), f["t"].double(), f["x_cond"].double(), f["mask"], f["y"].double())
+    assert rel_l2(out64, f["out64"]) < 1e-12
+
+
+def test_f2_shape_classes(golden):
+    f = golden("f2_shapes.npz")
+    names = sorted({k.split("/")[0] for k in f.raw.files})
+    assert len(names) == 5
+    for n in names:
+        g = f.group(n)
+        sh = shape_from({k[6:]: v for k, v in g.items() if k.startswith("shape.")})
+        p = latent_net.random_params(sh, seed=int(g["weight_seed"]))
+        out = latent_net.forward(p, sh, g["x"], g["t"], g["x_cond"], g["mask"], g.get("y"))
+        assert rel_l2(out, g["out"]) < 2e-6, n
+
+
+def test_f3_transport_scalars(golden):
+    f = golden("f3_transport.npz")
+    t, x, mo = f["t"], f["x"], f["model_out"]
+    model = lambda xx, tt, **kw: mo  # noqa: E731
+    for path in otr.PATHS:
+        for pred in otr.PREDICTIONS:
+            g = f.group(f"{path}.{pred}")
+            tr = otr.Transport(path, pred)
+            iv = []
+            for sde in (False, True):
+                for form in ("SBDM", "linear"):
+                    for ls in (0.0, 0.04):
+                        iv.append(list(map(float, tr.interval(diffusion_form=form, sde=sde, last_step_size=ls))))
+            assert torch.allclose(torch.tensor(iv, dtype=torch.float64), g["intervals"], atol=0, rtol=0)
+            assert rel_l2(tr.velocity(x, t, model), g["velocity"]) < 1e-6
+            assert rel_l2(tr.score(x, t, model), g["score"]) < 1e-6
+            for form in ("constant", "SBDM", "sigma", "linear", "decreasing", "inccreasing-decreasing"):
+                d = torch.as_tensor(tr.plan.diffusion(x, t, form, 0.7)) * torch.ones(13, 1, 1)
+                assert rel_l2(d, g["diff." + form]) < 1e-6
+
+
+def test_f3_error_behaviour():
+    import pytest
+    with pytest.raises(KeyError):
+        otr.Transport("nope", "data")
+    tr = otr.Transport("GVP", "data")
+    with pytest.raises(NotImplementedError):
+        tr.plan.diffusion(torch.zeros(1, 1), torch.ones(1) * 0.5, "bogus", 1.0)
+    assert tr.interval(sde=False) == (1e-3, 1 - 1e-3)
+    assert tr.interval(sde=True, diffusion_form="linear", last_step_size=0.04) == (1e-3, 1 - 0.04)
+    assert otr.Transport("Linear", "velocity").interval(sde=False) == (0, 1)
+
+
+def test_f4_samplers(golden):
+    f = golden("f4_sampler.npz")
+    sh = shape_from(f.group("shape"))
+    p = f.group("p")
+    init, xc, mask = f["init"], f["x_cond"], f["mask"]
+    tr = otr.Transport("GVP", "data")
+    for n in (2, 11, 51):
+        got = harness.sample_latents(p, sh, tr, init, xc, mask, None, "ODE", {"sampling_method": "euler", "num_steps": n})
+        assert rel_l2(got, f[f"ode{n}"]) < 5e-5, n
+    for path, pred in (("Linear", "velocity"), ("Linear", "data"), ("VP", "noise"), ("GVP", "score")):
+        got = harness.sample_latents(p, sh, otr.Transport(path, pred), init, xc, mask, None, "ODE",
+                                     {"sampling_method": "euler", "num_steps": 6})
+        assert rel_l2(got, f[f"ode6.{path}.{pred}"]) < 5e-5
+    model = lambda xt, t, **mk: latent_net.forward(p, sh, xt, t, **mk)  # noqa: E731
+    for n, form, last, meth in ((3, "linear", "Mean", "Euler"), (10, "linear", "Mean", "Euler"), (10, "SBDM", None, "Euler"),
+                                (6, "sigma", "Euler", "Euler"), (5, "linear", "Mean", "Heun"), (6, "decreasing", "Tweedie", "Euler")):
+        tag = f"sde{n}.{form}.{last}.{meth}"
+        noise = list(f[tag + ".noise"])
+        kw = {"sampling_method": meth, "diffusion_form": form, "last_step": last, "num_steps": n}
+        for single in (False, True):
+            xs = otr.get_sample_fn(tr, "SDE", kw, noise=noise, single_eval=single)(init, model, x_cond=xc, x_cond_mask=mask)
+            assert len(xs) == n
+            assert rel_l2(xs[-1], f[tag + ".final"]) < 5e-5, tag
+            assert rel_l2(xs[-2], f[tag + ".penultimate"]) < 5e-5, tag
+
+
+def test_f4_cfg1_full_shape(golden):
+    """True cfg-1 shape (T=30, L=192, C=32, D=256, H=16, depth 4), B=1, 10 Euler updates."""
+    f = golden("f4_cfg1.npz")
+    sh = shape_from(f.group("shape"))
+    p = latent_net.random_params(sh, seed=int(f["weight_seed"]))
+    g = torch.Generator().manual_seed(int(f["latent_seed"]))
+    lat = torch.randn(1, 30, 192, 32, generator=g)
+    xc, mask = harness.setup_conditioning(lat, tuple(f["cond_idx"].tolist()), True)
+    init = torch.randn(1, 30, 192, 32, generator=torch.Generator().manual_seed(int(f["init_seed"])))
+    got = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, mask, None, "ODE",
+                                 {"sampling_method": "euler", "num_steps": int(f["num_steps"])})
+    assert rel_l2(got, f["final"]) < 5e-5
+
+
+def test_f5_conditioning_bit_exact(golden):
+    f = golden("f5_cond.npz")
+    lat = f["latents"]
+    for mean in (True, False):
+        for ci in ((0, 3), (0, 1), (2, 5)):
+            xc, mask = harness.setup_conditioning(lat, ci, mean)
+            assert torch.equal(xc, f[f"m{int(mean)}.{ci[0]}_{ci[1]}.x_cond"])
+            assert torch.equal(mask, f[f"m{int(mean)}.{ci[0]}_{ci[1]}.mask"])
+
+
+def test_f6_decode(golden):
+    f = golden("f6_decode.npz")
+    pos = harness.decode(f.group("p"), harness.DecoderShape(), f["z"], f["entities"])
+    assert rel_l2(pos, f["pos"]) < 2e-6
