@@ -1,0 +1,17 @@
+"""lam_slide_amd: MI355X (gfx950) implementation of LaM-SLidE's second-stage latent SiT sampling path.
+
+Public surface (mirrors the reference's for this path only):
+  LatentSIV3                       <- src.models.components.latent.latent_si_v31.LatentSIV3
+  CreateTransport, Transport, Sampler, ModelType, PathType
+                                   <- src.modules.transport
+  SecondStageSampler, setup_conditioning, sample_sharded
+                                   <- SecondStageCondLightningBase.{sample, setup_conditioning} + batch sharding
+The compute lives in liblamslide_hip.so (include/lsl_api.h); build it with ``__graft_entry__.build()``.
+"""
+from . import _lib
+from .latent_si import LatentSIV3
+from .sampling import SecondStageSampler, sample_sharded, setup_conditioning, shard_bounds
+from .transport import CreateTransport, ModelType, PathType, Sampler, SampleResult, Transport, WeightType
+
+__all__ = ["LatentSIV3", "CreateTransport", "Transport", "Sampler", "SampleResult", "ModelType", "PathType", "WeightType",
+           "SecondStageSampler", "setup_conditioning", "sample_sharded", "shard_bounds", "_lib"]

@@ -1,0 +1,113 @@
+"""ctypes binding of liblamslide_hip.so (include/lsl_api.h).
+
+The HIP library is the only compute path of this package: importing works without it (so CPU-only
+tooling can read shapes and pack weights), but every call that would run the network raises
+``RuntimeError`` if the library is missing or the tensors are not on an AMD GPU.  There is no CPU
+fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblamslide_hip.so")
+SRC_DIR = os.path.join(_HERE, "csrc")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+EXPORTED = (
+    "lsl_version", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
+    "lsl_model_set_chunk", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_debug_block", "lsl_debug_mods",
+)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_dim", "hidden", "heads", "head_dim", "head_dim_pad", "mlp_dim", "depth",
+                                         "vec_in_dim", "normalize")] + [("theta", C.c_float)]
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "qs", "ks", "w2", "b2")]
+
+
+class Weights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "x_in_w", "x_in_b", "cond_w", "cond_b", "mask_emb", "time_freqs", "time_w1", "time_b1", "time_w2", "time_b2",
+        "vec_w1", "vec_b1", "vec_w2", "vec_b2", "mod_w", "mod_b", "out_w", "out_b")] + [("blocks", C.POINTER(BlockWeights))]
+
+
+class IO(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_cond", C.c_void_p), ("mask", C.c_void_p), ("y", C.c_void_p), ("t", C.c_void_p),
+                ("out", C.c_void_p), ("B", C.c_int32), ("T", C.c_int32), ("L", C.c_int32)]
+
+
+class Step(C.Structure):
+    _fields_ = [("t", C.c_float), ("ax", C.c_float), ("am", C.c_float), ("aw", C.c_float)]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR))] + [os.path.join(INCLUDE_DIR, "lsl_api.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", LIB_PATH, os.path.join(SRC_DIR, "lsl_api.hip")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout + res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed building liblamslide_hip.so")
+    return LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the library or fail loudly: the HIP path is the product, there is nothing to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP extension is the only compute path of lam_slide_amd)")
+    lib = C.CDLL(LIB_PATH)
+    lib.lsl_version.restype = C.c_int
+    lib.lsl_last_error.restype = C.c_char_p
+    lib.lsl_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]
+    lib.lsl_model_set_weights.argtypes = [C.c_void_p, C.POINTER(Weights)]
+    lib.lsl_model_destroy.argtypes = [C.c_void_p]
+    lib.lsl_model_destroy.restype = None
+    lib.lsl_model_set_chunk.argtypes = [C.c_void_p, C.c_int32]
+    lib.lsl_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.lsl_workspace_bytes.restype = C.c_size_t
+    lib.lsl_forward.argtypes = [C.c_void_p, C.POINTER(IO), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.lsl_sample.argtypes = [C.c_void_p, C.POINTER(IO), C.POINTER(Step), C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64,
+                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.lsl_debug_block.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.lsl_debug_mods.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]
+    if lib.lsl_version() != 1:
+        raise RuntimeError("liblamslide_hip.so version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().lsl_last_error().decode()
+
+
+def check(rc: int, shape_error=RuntimeError):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc in (-20, -21):
+        raise ValueError(msg)
+    if rc == -3:
+        raise ValueError(msg)
+    raise RuntimeError(f"lamslide_hip error {rc}: {msg}")

@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 kernels of the LaM-SLidE sampling path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T *
+
+// 32x32x16 bf16 MFMA, fp32 accumulate.  Operand maps (lane l: r = l & 31, hf = l >> 5):
+//   A[row r][k = 8 hf + j], B[k = 8 hf + j][col r], j = 0..7
+//   C/D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 hf, reg = 0..15
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int acc_row(int reg, int hf) { return (reg & 3) + 8 * (reg >> 2) + 4 * hf; }
+
+__device__ __forceinline__ u16 f2bf(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    return __builtin_bit_cast(u16, b);
+}
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Workgroup id remap so that consecutive logical tiles share an XCD's L2.  Hardware deals
+// workgroups round-robin over the 8 XCDs; this only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

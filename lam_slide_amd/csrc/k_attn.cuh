@@ -1,0 +1,147 @@
+// Softmax attention over one axis of the [B, T, L] token grid (mmdit.py:42-55: SDPA, no mask, scale
+// hd^-0.5), spatial (sequence = (b,t), positions l) or temporal (sequence = (b,l), positions t).  The
+// reference materialises "(B T) L D" / "(B L) T D" copies (latent_si_v31.py:51-61); here the axis is a
+// stride pattern over the token-major q/k/v buffer written by linear1's epilogue.
+//
+// One workgroup per ITEMS (sequence, head) pairs.  K and V of the pair are staged once in LDS
+// (K XOR-swizzled for ds_read_b128 fragments, V plain for ds_read_b64_tr_b16 transposed fragments).
+// Each wave owns 32-query tiles:
+//     St = K Q^T     (A = K rows, B = Q rows)   -> lane (q = l&31, hf) holds 16 of the tile's 32 keys
+//     online softmax in registers: running max / sum are per lane, one lane^32 exchange per tile
+//     Ot = V^T P^T   (A = V via transposed LDS read, B = P straight from the accumulator registers)
+// so every per-query quantity lives on the query's own lane.  q arrives pre-multiplied by
+// hd^-0.5 * log2(e) (linear1 epilogue), so probabilities are exp2(s - max).
+#pragma once
+#include "common.cuh"
+
+struct AttnArgs {
+    const u16 *qkv;  // [N][3*HHD] bf16 (q | k | v), head-major inside each third
+    u16 *z;          // [N][zw] bf16, attention output goes to columns [0, HHD)
+    int HHD, zw, H;
+    int S;           // sequence length (L or T)
+    int n_seq;       // number of sequences
+    // token of (seq, pos) = (seq / inner) * outer_stride + (seq % inner) + pos * pos_stride
+    int inner, outer_stride, pos_stride;
+};
+
+template <int HDP>
+__device__ __forceinline__ int k_swz(int row, int chunk) {
+    // 16-byte chunk swizzle making the 16-lane groups of ds_read_b128 hit distinct banks
+    if (HDP == 32) return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+    return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4);
+}
+
+template <int HDP, int NW, int ITEMS>
+__global__ void __launch_bounds__(NW * 64) k_attention(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = HDP * 2;         // bytes per K/V row
+    constexpr int CPR = ROWB / 16;        // 16-byte chunks per row
+    constexpr int KS = HDP / 16;          // k-steps of the QK^T contraction
+    constexpr int WPI = NW / ITEMS;       // waves per (seq, head) item
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int S = a.S, Sp = (S + 31) & ~31, nkt = Sp >> 5;
+    const int item_local = wave / WPI, wsub = wave % WPI;
+    const long item = (long)blockIdx.x * ITEMS + item_local;
+    const bool item_ok = item < (long)a.n_seq * a.H;
+    const int seq = item_ok ? (int)(item / a.H) : 0, head = item_ok ? (int)(item % a.H) : 0;
+    const size_t tok0 = (size_t)(seq / a.inner) * a.outer_stride + (seq % a.inner);
+    const size_t rs = (size_t)3 * a.HHD;  // qkv row stride (elements)
+    char *Ks = smem + (size_t)item_local * 2 * Sp * ROWB;
+    char *Vs = Ks + (size_t)Sp * ROWB;
+
+    // stage K (swizzled) and V (plain); rows >= S are zero so padded keys contribute exactly 0 * 0
+    {
+        const int ltid = wsub * 64 + lane, lthreads = WPI * 64;
+        const u16 *kbase = a.qkv + tok0 * rs + a.HHD + head * HDP;
+        const u16 *vbase = kbase + a.HHD;
+        for (int i = ltid; i < Sp * CPR; i += lthreads) {
+            const int row = i / CPR, ch = i % CPR;
+            u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (row < S && item_ok) {
+                const size_t off = (size_t)row * a.pos_stride * rs + ch * 8;
+                kv = *reinterpret_cast<const u32x4 *>(kbase + off);
+                vv = *reinterpret_cast<const u32x4 *>(vbase + off);
+            }
+            *reinterpret_cast<u32x4 *>(Ks + k_swz<HDP>(row, ch)) = kv;
+            *reinterpret_cast<u32x4 *>(Vs + row * ROWB + ch * 16) = vv;
+        }
+    }
+    __syncthreads();
+
+    // transposed-read lane geometry (ds_read_b64_tr_b16, per 16-lane group: lane 4q+p supplies row q,
+    // columns 4p..4p+3 of a 4x16 block; lane i receives column i of the 4 rows)
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, grp = lane >> 4;
+    const int v_col = (HDP == 32 ? (grp & 1) * 16 : 0) + 4 * gp;
+    const int v_row0 = 4 * (grp >> 1) + gq;  // + 16*s + 8*half + 32*kt
+
+    for (int qt = wsub; qt < nkt; qt += WPI) {
+        // Q fragments straight from global memory (B operand: Q[q = r][hd = 16 s + 8 hf + j])
+        const int qpos = min(qt * 32 + r, S - 1);
+        const u16 *qrow = a.qkv + (tok0 + (size_t)qpos * a.pos_stride) * rs + head * HDP;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qrow + 16 * s + 8 * hf));
+
+        f32x16 o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.0f;
+        float m_run = -INFINITY, l_run = 0.0f;
+
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 sacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[e] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(kt * 32 + r, (KS == 2 ? 2 * s : 0) + hf)));
+                sacc = mfma32(kf, qf[s], sacc);
+            }
+            if (kt * 32 + 32 > S) {  // wave-uniform: mask the zero-padded keys of the last tile
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kt * 32 + acc_row(e, hf) >= S) sacc[e] = -INFINITY;
+            }
+            float mt = sacc[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sacc[e]);
+            mt = fmaxf(mt, xhalf(mt));
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = exp2f(m_run - m_new);
+            float psum = 0.0f;
+            float p[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                p[e] = exp2f(sacc[e] - m_new);
+                psum += p[e];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // B operand: P[q][key], element j of k-step s = accumulator register 8 s + j
+                u32x4 pw = {pack2(p[8 * s], p[8 * s + 1]), pack2(p[8 * s + 2], p[8 * s + 3]),
+                            pack2(p[8 * s + 4], p[8 * s + 5]), pack2(p[8 * s + 6], p[8 * s + 7])};
+                // A operand: V^T[hd = r][key], same key order: element j <-> key 16 s + 8 (j>>2) + 4 hf + (j&3)
+                const int vr = kt * 32 + 16 * s + v_row0;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(Vs + vr * ROWB + v_col * 2));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(Vs + (vr + 8) * ROWB + v_col * 2));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o = mfma32(__builtin_bit_cast(bf16x8, vv), as_bf16x8(pw), o);
+            }
+        }
+        const float inv_l = 1.0f / (l_run + xhalf(l_run));
+        const int qglob = qt * 32 + r;
+        if (qglob < S && item_ok) {
+            u16 *dst = a.z + (tok0 + (size_t)qglob * a.pos_stride) * a.zw + head * HDP;
+#pragma unroll
+            for (int q4 = 0; q4 < HDP / 8; ++q4) {
+                u32x2 pk = {pack2(o[4 * q4] * inv_l, o[4 * q4 + 1] * inv_l), pack2(o[4 * q4 + 2] * inv_l, o[4 * q4 + 3] * inv_l)};
+                *reinterpret_cast<u32x2 *>(dst + 8 * q4 + 4 * hf) = pk;
+            }
+        }
+    }
+}

@@ -1,0 +1,208 @@
+// bf16 MFMA GEMM for linear1 / linear2 of a ParallelMLPAttentionV2 block (mmdit.py:240-249), with the
+// surrounding element-wise work fused into the epilogue.
+//
+// Orientation: the kernel computes the TRANSPOSED product  Ct[f][n] = sum_k W[f][k] * X[n][k]
+// (W = nn.Linear weight [out,in], X = activations [tokens, in]; both are k-contiguous, so both MFMA
+// operands are plain 16-byte row reads).  With features on the accumulator rows and tokens on the
+// lanes, one lane holds 16 of the 32 features of a tile for ONE token: per-head RMS norm and the RoPE
+// pair rotation are in-register (+ one exchange with lane^32), and every store is 4 consecutive
+// features of one token.
+//
+// Tiling: workgroup tile BF x BT (features x tokens), BK = 64, NWF x NWT waves, each wave owns
+// (BF/NWF) x (BT/NWT) as 32x32 MFMA tiles.  LDS double buffer, register-staged global loads
+// (issue early / write late), XOR-swizzled 16-byte chunks so ds_read_b128 fragment reads are
+// conflict-free:  physical chunk = chunk ^ ((row >> 1) & 7)  for 128-byte rows.
+#pragma once
+#include "common.cuh"
+
+constexpr int GEMM_BK = 64;
+
+struct GemmArgs {
+    const u16 *W;  // [F][K] bf16
+    const u16 *X;  // [N][K] bf16
+    int F, N, K;
+};
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {  // byte offset inside a [rows][64] bf16 tile
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <int BF, int BT, int NWF, int NWT, class Epi>
+__global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_wx(GemmArgs g, Epi epi) {
+    constexpr int NT = NWF * NWT * 64;
+    constexpr int WF = BF / NWF, WT = BT / NWT;  // wave tile
+    constexpr int MI = WF / 32, NJ = WT / 32;    // MFMA tiles per wave
+    constexpr int W_LOADS = BF * 8 / NT, X_LOADS = BT * 8 / NT;  // 16-byte chunks per thread per k-tile
+    static_assert(BF * 8 % NT == 0 && BT * 8 % NT == 0, "tile/threads mismatch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Ws = smem;                           // [2][BF][64] bf16
+    char *Xs = smem + 2 * BF * 128;            // [2][BT][64] bf16
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wf = wave / NWT, wt = wave % NWT;
+    const int r = lane & 31, hf = lane >> 5;
+
+    const int ntt = (g.N + BT - 1) / BT, nft = (g.F + BF - 1) / BF;
+    const int tile = xcd_remap(blockIdx.x, ntt * nft);
+    const int f_base = (tile % nft) * BF, n_base = (tile / nft) * BT;
+
+    // global -> register staging: thread covers row (tid/8 + i*NT/8), chunk tid%8
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    u32x4 wreg[W_LOADS], xreg[X_LOADS];
+    const u16 *wsrc[W_LOADS];
+    const u16 *xsrc[X_LOADS];
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+        const int f = min(f_base + lrow + i * (NT / 8), g.F - 1);
+        wsrc[i] = g.W + (size_t)f * g.K + lchunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < X_LOADS; ++i) {
+        const int n = min(n_base + lrow + i * (NT / 8), g.N - 1);
+        xsrc[i] = g.X + (size_t)n * g.K + lchunk * 8;
+    }
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) wreg[i] = *reinterpret_cast<const u32x4 *>(wsrc[i] + kt * GEMM_BK);
+#pragma unroll
+        for (int i = 0; i < X_LOADS; ++i) xreg[i] = *reinterpret_cast<const u32x4 *>(xsrc[i] + kt * GEMM_BK);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i)
+            *reinterpret_cast<u32x4 *>(Ws + buf * BF * 128 + swz_off(lrow + i * (NT / 8), lchunk)) = wreg[i];
+#pragma unroll
+        for (int i = 0; i < X_LOADS; ++i)
+            *reinterpret_cast<u32x4 *>(Xs + buf * BT * 128 + swz_off(lrow + i * (NT / 8), lchunk)) = xreg[i];
+    };
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = g.K / GEMM_BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char *wb = Ws + buf * BF * 128, *xb = Xs + buf * BT * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(wb + swz_off(wf * WF + i * 32 + r, 2 * ks + hf)));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xb + swz_off(wt * WT + j * 32 + r, 2 * ks + hf)));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int f0 = f_base + wf * WF + i * 32;
+        if (f0 >= g.F) continue;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n_base + wt * WT + j * 32 + r;
+            epi(acc[i][j], f0, n, hf, n < g.N);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// linear1 epilogue: + bias; q/k heads: RMS norm * scale, RoPE (q additionally * softmax scale * log2 e);
+// v: as is; mlp: exact-erf GELU.  Output bf16:  qkv[n][0 .. 3*HHD)  and  z[n][HHD .. HHD+M).
+// (mmdit.py:241-248, 129-148, 85-90, 11-18)
+template <int HDP>
+struct EpiLinear1 {
+    const float *bias;     // [F1]
+    const float *qs, *ks;  // [HDP]
+    const float2 *rope;    // [n_pos][HDP/2] (cos, sin)
+    u16 *qkv;              // [N][3*HHD]
+    u16 *z;                // [N][HHD + M]
+    int HHD, M;
+    int pos_div, pos_mod;  // position of token n inside its sequence: (n / pos_div) % pos_mod
+    float inv_hd;          // 1 / true head_dim
+    float q_premul;        // head_dim^-0.5 * log2(e), folded into q for the exp2-based softmax
+
+    __device__ __forceinline__ void operator()(const f32x16 &acc, int f0, int n, int hf, bool valid) const {
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = acc[e] + bias[f0 + acc_row(e, hf)];
+        const int sec = f0 / HHD;  // 0 q, 1 k, 2 v, >= 3 mlp (wave-uniform: HHD is a multiple of 32)
+        if (sec < 2) {
+            const float *sc = sec == 0 ? qs : ks;
+            const int pos = (n / pos_div) % pos_mod;
+            const float2 *tab = rope + (size_t)pos * (HDP / 2);
+            constexpr int GROUPS = 32 / HDP;      // heads per 32-feature tile
+            constexpr int RPG = 16 / GROUPS;      // registers per head
+#pragma unroll
+            for (int gi = 0; gi < GROUPS; ++gi) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int e = 0; e < RPG; ++e) ss += v[gi * RPG + e] * v[gi * RPG + e];
+                ss += xhalf(ss);
+                const float rr = rsqrtf(ss * inv_hd + 1e-6f);
+#pragma unroll
+                for (int e = 0; e < RPG; e += 2) {
+                    const int d = acc_row(gi * RPG + e, hf) & (HDP - 1);  // even channel inside the head
+                    const float x0 = v[gi * RPG + e] * rr * sc[d], x1 = v[gi * RPG + e + 1] * rr * sc[d + 1];
+                    const float2 cs = valid ? tab[d >> 1] : make_float2(1.0f, 0.0f);
+                    float y0 = cs.x * x0 - cs.y * x1, y1 = cs.y * x0 + cs.x * x1;
+                    if (sec == 0) { y0 *= q_premul; y1 *= q_premul; }
+                    v[gi * RPG + e] = y0;
+                    v[gi * RPG + e + 1] = y1;
+                }
+            }
+        } else if (sec >= 3) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (!valid) return;
+        u16 *dst = sec < 3 ? qkv + (size_t)n * (3 * HHD) + f0 : z + (size_t)n * (HHD + M) + (f0 - 2 * HHD);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            u32x2 pk = {pack2(v[4 * q4], v[4 * q4 + 1]), pack2(v[4 * q4 + 2], v[4 * q4 + 3])};
+            *reinterpret_cast<u32x2 *>(dst + 8 * q4 + 4 * hf) = pk;
+        }
+    }
+};
+
+// linear2 epilogue: h[n][f] += gate[b][f] * (acc + bias[f])   (latent_si_v31.py:53,60; fp32 residual)
+struct EpiLinear2 {
+    const float *bias;  // [D]
+    const float *gate;  // mods + gate offset, row stride mod_stride
+    float *h;           // [N][D]
+    int D, mod_stride, tokens_per_traj;
+
+    __device__ __forceinline__ void operator()(const f32x16 &acc, int f0, int n, int hf, bool valid) const {
+        if (!valid) return;
+        const float *gr = gate + (size_t)(n / tokens_per_traj) * mod_stride;
+        float *hr = h + (size_t)n * D;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int f = f0 + 8 * q4 + 4 * hf;
+            const float4 b = *reinterpret_cast<const float4 *>(bias + f);
+            const float4 gt = *reinterpret_cast<const float4 *>(gr + f);
+            float4 hv = *reinterpret_cast<float4 *>(hr + f);
+            hv.x = fmaf(gt.x, acc[4 * q4] + b.x, hv.x);
+            hv.y = fmaf(gt.y, acc[4 * q4 + 1] + b.y, hv.y);
+            hv.z = fmaf(gt.z, acc[4 * q4 + 2] + b.z, hv.z);
+            hv.w = fmaf(gt.w, acc[4 * q4 + 3] + b.w, hv.w);
+            *reinterpret_cast<float4 *>(hr + f) = hv;
+        }
+    }
+};

@@ -1,0 +1,446 @@
+// Host side of liblamslide_hip.so: the C ABI of include/lsl_api.h.  Enqueues the kernel sequence of one
+// network evaluation (latent_si_v31.py:168-188) and of the sampler loops (integrators.py:67-78,103-120)
+// on the caller's stream.  No allocation, no synchronisation, no host<->device copies.
+#include "../../include/lsl_api.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "k_attn.cuh"
+#include "k_gemm.cuh"
+#include "k_small.cuh"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define LSL_CHECK_LAUNCH(name)                                                     \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) return fail(-10, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct lsl_model {
+    lsl_model_desc d;
+    lsl_weights w;
+    std::vector<lsl_block_weights> blocks;
+    bool has_weights = false;
+    int chunk = 0;
+    int HHD, F1, K2, MODW;
+};
+
+namespace {
+
+struct Workspace {
+    float2 *rope_l, *rope_t;
+    float *cond_emb, *h, *yemb, *tfeat, *hid, *vec, *mods;
+    u16 *a, *qkv, *z;
+    size_t bytes;
+};
+
+// Scratch layout for a pass over `bc` trajectories.
+Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
+    const lsl_model_desc &d = m->d;
+    const size_t n = (size_t)bc * T * L, D = d.hidden;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align_up(bytes, 256);
+        return p;
+    };
+    Workspace ws;
+    ws.rope_l = (float2 *)take((size_t)L * (d.head_dim_pad / 2) * sizeof(float2));
+    ws.rope_t = (float2 *)take((size_t)T * (d.head_dim_pad / 2) * sizeof(float2));
+    ws.cond_emb = (float *)take(n * D * 4);
+    ws.h = (float *)take(n * D * 4);
+    ws.yemb = (float *)take((size_t)bc * D * 4);
+    ws.tfeat = (float *)take((size_t)bc * 256 * 4);
+    ws.hid = (float *)take((size_t)bc * D * 4);
+    ws.vec = (float *)take((size_t)bc * D * 4);
+    ws.mods = (float *)take((size_t)bc * m->MODW * 4);
+    ws.a = (u16 *)take(n * D * 2);
+    ws.qkv = (u16 *)take(n * 3 * m->HHD * 2);
+    ws.z = (u16 *)take(n * m->K2 * 2);
+    ws.bytes = off;
+    return ws;
+}
+
+int default_chunk(const lsl_model *m, int B, int T, int L) {
+    if (m->chunk > 0) return m->chunk < B ? m->chunk : B;
+    if (const char *e = getenv("LSL_CHUNK_TRAJ")) {
+        const int v = atoi(e);
+        if (v > 0) return v < B ? v : B;
+    }
+    // keep one pass's activations (about 18 D + 2 M bytes per token) near the 256 MiB Infinity Cache
+    const size_t per_traj = (size_t)T * L * (18 * m->d.hidden + 2 * m->d.mlp_dim);
+    size_t c = ((size_t)192 << 20) / (per_traj ? per_traj : 1);
+    if (c < 1) c = 1;
+    return (int)(c < (size_t)B ? c : (size_t)B);
+}
+
+template <typename K>
+void allow_lds(K kernel, size_t bytes) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// ---- launch helpers -------------------------------------------------------------------------------
+
+template <int NE, int VEC>
+void launch_ln_mod_t(u16 *a, const float *h, const float *shift, const float *scale, int stride, int n, int tpt, hipStream_t st) {
+    hipLaunchKernelGGL((k_ln_modulate<NE, VEC>), dim3((n + 3) / 4), dim3(256), 0, st, a, h, shift, scale, stride, n, tpt);
+}
+template <int NE, int VEC>
+void launch_ln_inplace_t(float *h, int n, float eps, hipStream_t st) {
+    hipLaunchKernelGGL((k_ln_inplace<NE, VEC>), dim3((n + 3) / 4), dim3(256), 0, st, h, n, eps);
+}
+template <int NE, int VEC>
+void launch_head_t(float *x, float *out, const float *h, const float *shift, const float *scale, int stride, const float *Wo,
+                   const float *bo, int n, int C, int tpt, int do_step, float ax, float am, float aw, const float *noise,
+                   unsigned long long seed, unsigned step, unsigned long long eo, float *trace, hipStream_t st) {
+    hipLaunchKernelGGL((k_head_step<NE, VEC>), dim3((n + 3) / 4), dim3(256), 0, st, x, out, h, shift, scale, stride, Wo, bo, n,
+                       C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
+}
+
+#define DISPATCH_D(D, FN, ...)                          \
+    switch ((D) / 64) {                                 \
+        case 1: FN<1, 1>(__VA_ARGS__); break;           \
+        case 2: FN<2, 2>(__VA_ARGS__); break;           \
+        case 3: FN<3, 1>(__VA_ARGS__); break;           \
+        case 4: FN<4, 2>(__VA_ARGS__); break;           \
+        case 5: FN<5, 1>(__VA_ARGS__); break;           \
+        case 6: FN<6, 2>(__VA_ARGS__); break;           \
+        case 7: FN<7, 1>(__VA_ARGS__); break;           \
+        default: FN<8, 2>(__VA_ARGS__); break;          \
+    }
+
+template <int MODE>
+int launch_embed(float *out, const float *in, const float *W, const float *b, const float *b2, const float *me,
+                 const int64_t *mask, const float *base, int n, int C, int D, hipStream_t st) {
+    const dim3 grid((n + 31) / 32), blk(D < 256 ? D : 256);
+    if (C <= 32) hipLaunchKernelGGL((k_embed<32, MODE>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
+    else if (C <= 64) hipLaunchKernelGGL((k_embed<64, MODE>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
+    else if (C <= 96) hipLaunchKernelGGL((k_embed<96, MODE>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
+    else hipLaunchKernelGGL((k_embed<128, MODE>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
+    return 0;
+}
+
+template <class Epi>
+void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi, hipStream_t st) {
+    constexpr int BF = 128, BT = 128;
+    auto kern = k_gemm_wx<BF, BT, 2, 2, Epi>;
+    const size_t lds = 2 * (BF + BT) * 128;
+    static bool once = (allow_lds(kern, lds), true);
+    (void)once;
+    const int tiles = ((N + BT - 1) / BT) * ((F + BF - 1) / BF);
+    GemmArgs g{W, X, F, N, K};
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, g, epi);
+}
+
+template <int HDP>
+void launch_attention_t(const AttnArgs &a, hipStream_t st) {
+    const int Sp = (a.S + 31) & ~31;
+    const long items = (long)a.n_seq * a.H;
+    const size_t per_item = (size_t)2 * Sp * HDP * 2;
+    if (Sp <= 32) {
+        auto kern = k_attention<HDP, 4, 4>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), 4 * per_item, st, a);
+    } else if (Sp <= 64) {
+        auto kern = k_attention<HDP, 4, 2>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((items + 1) / 2)), dim3(256), 2 * per_item, st, a);
+    } else if (Sp <= 512) {
+        auto kern = k_attention<HDP, 4, 1>;
+        static bool once = (allow_lds(kern, 65536), true);
+        (void)once;
+        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(256), per_item, st, a);
+    } else {
+        auto kern = k_attention<HDP, 8, 1>;
+        static bool once = (allow_lds(kern, 160 * 1024), true);
+        (void)once;
+        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), per_item, st, a);
+    }
+}
+
+// ---- pieces of one evaluation ----------------------------------------------------------------------
+
+// conditioning vector -> all modulation tables for `rows` trajectories (latent_si_v31.py:176-178,
+// mmdit.py:184-197).  t_dev == nullptr: scalar t.  yemb == nullptr: no class conditioning.
+int run_mods(const lsl_model *m, const Workspace &ws, const float *t_dev, float t_scalar, const float *yemb, int rows,
+             float *vec_out, float *mods_out, hipStream_t st) {
+    const lsl_weights &w = m->w;
+    const int D = m->d.hidden;
+    hipLaunchKernelGGL(k_time_features, dim3((rows * 128 + 255) / 256), dim3(256), 0, st, ws.tfeat, t_dev, t_scalar, w.time_freqs, rows);
+    hipLaunchKernelGGL((k_dense_rows<false, true>), dim3((D + 3) / 4), dim3(256), 0, st, ws.hid, ws.tfeat, w.time_w1, w.time_b1,
+                       (const float *)nullptr, rows, 256, D, 0);
+    hipLaunchKernelGGL((k_dense_rows<false, false>), dim3((D + 3) / 4), dim3(256), 0, st, vec_out, ws.hid, w.time_w2, w.time_b2, yemb,
+                       rows, D, D, D);
+    hipLaunchKernelGGL((k_dense_rows<true, false>), dim3((m->MODW + 3) / 4), dim3(256), 0, st, mods_out, vec_out, w.mod_w, w.mod_b,
+                       (const float *)nullptr, rows, D, m->MODW, 0);
+    LSL_CHECK_LAUNCH("modulation");
+    return 0;
+}
+
+// vec_in(y) (mmdit.py:118-126), constant over a sample
+int run_yemb(const lsl_model *m, const Workspace &ws, const float *y, int rows, hipStream_t st) {
+    const lsl_weights &w = m->w;
+    const int D = m->d.hidden, V = m->d.vec_in_dim;
+    hipLaunchKernelGGL((k_dense_rows<false, true>), dim3((D + 3) / 4), dim3(256), 0, st, ws.hid, y, w.vec_w1, w.vec_b1,
+                       (const float *)nullptr, rows, V, D, 0);
+    hipLaunchKernelGGL((k_dense_rows<false, false>), dim3((D + 3) / 4), dim3(256), 0, st, ws.yemb, ws.hid, w.vec_w2, w.vec_b2,
+                       (const float *)nullptr, rows, D, D, 0);
+    LSL_CHECK_LAUNCH("vec_in");
+    return 0;
+}
+
+void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream_t st) {
+    const int half = m->d.head_dim_pad / 2;
+    hipLaunchKernelGGL(k_rope_table, dim3((L * half + 255) / 256), dim3(256), 0, st, ws.rope_l, L, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
+    hipLaunchKernelGGL(k_rope_table, dim3((T * half + 255) / 256), dim3(256), 0, st, ws.rope_t, T, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
+}
+
+// one ParallelMLPAttentionV2 sub-block on h (in place): LN+modulate -> linear1 -> attention -> linear2
+int run_block(const lsl_model *m, const Workspace &ws, int bi, float *h, const float *mods, int mod_stride, int bc, int T, int L,
+              hipStream_t st) {
+    const lsl_model_desc &d = m->d;
+    const lsl_block_weights &bw = m->blocks[bi];
+    const int D = d.hidden, n = bc * T * L, layer = bi / 2, temporal = bi & 1;
+    const float *mbase = mods + (size_t)layer * 6 * D + (temporal ? 3 * D : 0);  // shift, scale, gate
+    DISPATCH_D(D, launch_ln_mod_t, ws.a, h, mbase, mbase + D, mod_stride, n, T * L, st);
+
+    const float premul = (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
+    if (d.head_dim_pad == 32) {
+        EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
+                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul};
+        launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st);
+    } else {
+        EpiLinear1<16> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
+                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul};
+        launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st);
+    }
+    AttnArgs aa;
+    aa.qkv = ws.qkv;
+    aa.z = ws.z;
+    aa.HHD = m->HHD;
+    aa.zw = m->K2;
+    aa.H = d.heads;
+    if (!temporal) {  // sequences (b,t), positions l
+        aa.S = L; aa.n_seq = bc * T; aa.inner = 1; aa.outer_stride = L; aa.pos_stride = 1;
+    } else {          // sequences (b,l), positions t
+        aa.S = T; aa.n_seq = bc * L; aa.inner = L; aa.outer_stride = T * L; aa.pos_stride = L;
+    }
+    if (d.head_dim_pad == 32) launch_attention_t<32>(aa, st);
+    else launch_attention_t<16>(aa, st);
+
+    EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L};
+    launch_gemm((const u16 *)bw.w2, ws.z, D, n, m->K2, e2, st);
+    LSL_CHECK_LAUNCH("block");
+    return 0;
+}
+
+// One evaluation for a pass of bc trajectories; state already embedded?  No: embeds x first.
+// do_step: fuse the affine update into the head; else write the network output to `out`.
+int run_eval(const lsl_model *m, const Workspace &ws, float *x, float *out, const float *t_dev, float t_scalar, bool have_y, int bc,
+             int T, int L, int do_step, float ax, float am, float aw, const float *noise, uint64_t seed, unsigned step,
+             uint64_t elem_off, float *trace, hipStream_t st) {
+    const lsl_model_desc &d = m->d;
+    const int D = d.hidden, n = bc * T * L;
+    // modulation rows: one per trajectory, or a single shared row when t is a scalar and there is no y
+    const bool shared = (t_dev == nullptr) && !have_y;
+    const int rows = shared ? 1 : bc;
+    const int mod_stride = shared ? 0 : m->MODW;
+    int rc = run_mods(m, ws, t_dev, t_scalar, have_y ? ws.yemb : nullptr, rows, ws.vec, ws.mods, st);
+    if (rc) return rc;
+    launch_embed<1>(ws.h, x, m->w.x_in_w, nullptr, nullptr, nullptr, nullptr, ws.cond_emb, n, d.in_dim, D, st);
+    if (d.normalize) { DISPATCH_D(D, launch_ln_inplace_t, ws.h, n, 1e-5f, st); }
+    LSL_CHECK_LAUNCH("embed");
+    for (int bi = 0; bi < 2 * d.depth; ++bi) {
+        rc = run_block(m, ws, bi, ws.h, ws.mods, mod_stride, bc, T, L, st);
+        if (rc) return rc;
+    }
+    const float *fm = ws.mods + (size_t)d.depth * 6 * D;  // adaLN: shift, scale
+    DISPATCH_D(D, launch_head_t, x, out, ws.h, fm, fm + D, mod_stride, m->w.out_w, m->w.out_b, n, d.in_dim, T * L, do_step, ax, am, aw,
+               noise, (unsigned long long)seed, step, (unsigned long long)elem_off, trace, st);
+    LSL_CHECK_LAUNCH("head");
+    return 0;
+}
+
+int prepare_pass(const lsl_model *m, const Workspace &ws, const float *x_cond, const int64_t *mask, const float *y, int bc, int T,
+                 int L, hipStream_t st) {
+    const lsl_model_desc &d = m->d;
+    const int n = bc * T * L;
+    launch_embed<0>(ws.cond_emb, x_cond, m->w.cond_w, m->w.cond_b, m->w.x_in_b, m->w.mask_emb, mask, nullptr, n, d.in_dim, d.hidden, st);
+    LSL_CHECK_LAUNCH("cond_embed");
+    if (y) return run_yemb(m, ws, y, bc, st);
+    return 0;
+}
+
+int check_call(const lsl_model *m, const lsl_io *io, size_t ws_bytes, void *ws, int *chunk_out) {
+    if (!m || !io) return fail(-1, "null model or io");
+    if (!m->has_weights) return fail(-2, "weights not set");
+    if (io->B <= 0 || io->T <= 0 || io->L <= 0) return fail(-3, "B, T, L must be positive");
+    if (!io->x || !io->x_cond || !io->mask) return fail(-3, "x, x_cond and mask are required");
+    if ((io->y != nullptr) != (m->d.vec_in_dim > 0) && io->y != nullptr) return fail(-3, "y given but the model has no vec_in");
+    if ((size_t)io->T * io->L > (1u << 24)) return fail(-3, "T*L too large");
+    const int chunk = default_chunk(m, io->B, io->T, io->L);
+    const size_t need = carve(m, nullptr, chunk, io->T, io->L).bytes;
+    if (!ws || ws_bytes < need) return fail(-4, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
+    *chunk_out = chunk;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lsl_version(void) { return LSL_VERSION; }
+const char *lsl_last_error(void) { return g_err; }
+
+int lsl_model_create(const lsl_model_desc *desc, lsl_model **out) {
+    if (!desc || !out) return fail(-1, "null argument");
+    const lsl_model_desc &d = *desc;
+    if (d.heads <= 0 || d.hidden % d.heads != 0)
+        return fail(-20, "Hidden size %d must be divisible by num_heads %d", d.hidden, d.heads);  // latent_si_v31.py:92-95
+    if (d.head_dim != d.hidden / d.heads) return fail(-21, "head_dim must equal hidden / heads");
+    if (d.hidden % 64 != 0 || d.hidden < 64 || d.hidden > 512) return fail(-21, "hidden_size %d unsupported (multiple of 64, 64..512)", d.hidden);
+    if (d.head_dim % 2 != 0 || d.head_dim > 32) return fail(-21, "head_dim %d unsupported (even, <= 32)", d.head_dim);
+    if (d.head_dim_pad != (d.head_dim <= 16 ? 16 : 32)) return fail(-21, "head_dim_pad must be 16 (head_dim <= 16) or 32");
+    if ((d.heads * d.head_dim_pad) % 32 != 0) return fail(-21, "heads * head_dim_pad must be a multiple of 32");
+    if (d.mlp_dim <= 0 || d.mlp_dim % 32 != 0) return fail(-21, "mlp_dim %d must be a positive multiple of 32", d.mlp_dim);
+    if ((d.heads * d.head_dim_pad + d.mlp_dim) % 64 != 0) return fail(-21, "heads*head_dim_pad + mlp_dim must be a multiple of 64");
+    if (d.in_dim <= 0 || d.in_dim > 128) return fail(-21, "in_dim %d unsupported (1..128)", d.in_dim);
+    if (d.depth <= 0 || d.depth > 64) return fail(-21, "depth %d unsupported", d.depth);
+    if (d.vec_in_dim < 0 || d.vec_in_dim > 512) return fail(-21, "vec_in_dim %d unsupported (<= 512)", d.vec_in_dim);
+    lsl_model *m = new (std::nothrow) lsl_model();
+    if (!m) return fail(-5, "out of host memory");
+    m->d = d;
+    m->HHD = d.heads * d.head_dim_pad;
+    m->F1 = 3 * m->HHD + d.mlp_dim;
+    m->K2 = m->HHD + d.mlp_dim;
+    m->MODW = (6 * d.depth + 2) * d.hidden;
+    *out = m;
+    return 0;
+}
+
+int lsl_model_set_weights(lsl_model *m, const lsl_weights *w) {
+    if (!m || !w || !w->blocks) return fail(-1, "null argument");
+    const void *req[] = {w->x_in_w, w->x_in_b, w->cond_w, w->cond_b, w->mask_emb, w->time_freqs, w->time_w1, w->time_b1,
+                         w->time_w2, w->time_b2, w->mod_w, w->mod_b, w->out_w, w->out_b};
+    for (const void *p : req)
+        if (!p) return fail(-2, "missing weight pointer");
+    if (m->d.vec_in_dim > 0 && (!w->vec_w1 || !w->vec_b1 || !w->vec_w2 || !w->vec_b2)) return fail(-2, "missing vec_in weights");
+    m->blocks.assign(w->blocks, w->blocks + 2 * m->d.depth);
+    for (const auto &b : m->blocks)
+        if (!b.w1 || !b.b1 || !b.qs || !b.ks || !b.w2 || !b.b2) return fail(-2, "missing block weight pointer");
+    m->w = *w;
+    m->w.blocks = m->blocks.data();
+    m->has_weights = true;
+    return 0;
+}
+
+void lsl_model_destroy(lsl_model *m) { delete m; }
+
+int lsl_model_set_chunk(lsl_model *m, int32_t c) {
+    if (!m || c < 0) return fail(-1, "bad argument");
+    m->chunk = c;
+    return 0;
+}
+
+size_t lsl_workspace_bytes(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
+    if (!m || B <= 0 || T <= 0 || L <= 0) return 0;
+    return carve(m, nullptr, default_chunk(m, B, T, L), T, L).bytes;
+}
+
+int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspace_bytes, void *stream) {
+    int chunk = 0;
+    if (int rc = check_call(m, io, workspace_bytes, workspace, &chunk)) return rc;
+    if (!io->t || !io->out) return fail(-3, "t and out are required");
+    hipStream_t st = (hipStream_t)stream;
+    const Workspace ws = carve(m, (char *)workspace, chunk, io->T, io->L);
+    run_tables(m, ws, io->T, io->L, st);
+    const size_t per = (size_t)io->T * io->L * m->d.in_dim;
+    for (int b0 = 0; b0 < io->B; b0 += chunk) {
+        const int bc = io->B - b0 < chunk ? io->B - b0 : chunk;
+        const float *y = io->y ? io->y + (size_t)b0 * m->d.vec_in_dim : nullptr;
+        if (int rc = prepare_pass(m, ws, io->x_cond + b0 * per, io->mask + (size_t)b0 * io->T * io->L, y, bc, io->T, io->L, st)) return rc;
+        if (int rc = run_eval(m, ws, io->x + b0 * per, io->out + b0 * per, io->t + b0, 0.0f, y != nullptr, bc, io->T, io->L, 0, 0, 0, 0,
+                              nullptr, 0, 0, 0, nullptr, st))
+            return rc;
+    }
+    return 0;
+}
+
+int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, int32_t n_noise, uint64_t seed,
+               uint64_t elem_offset, float *trace, void *workspace, size_t workspace_bytes, void *stream) {
+    int chunk = 0;
+    if (int rc = check_call(m, io, workspace_bytes, workspace, &chunk)) return rc;
+    if (!steps || n_steps <= 0) return fail(-3, "steps required");
+    if (noise)
+        for (int s = n_noise < 0 ? 0 : n_noise; s < n_steps; ++s)
+            if (steps[s].aw != 0.0f) return fail(-3, "step %d needs noise but only %d slices were given", s, n_noise);
+    hipStream_t st = (hipStream_t)stream;
+    const Workspace ws = carve(m, (char *)workspace, chunk, io->T, io->L);
+    run_tables(m, ws, io->T, io->L, st);
+    const size_t per = (size_t)io->T * io->L * m->d.in_dim;
+    const size_t total = per * io->B;
+    for (int b0 = 0; b0 < io->B; b0 += chunk) {
+        const int bc = io->B - b0 < chunk ? io->B - b0 : chunk;
+        const float *y = io->y ? io->y + (size_t)b0 * m->d.vec_in_dim : nullptr;
+        if (int rc = prepare_pass(m, ws, io->x_cond + b0 * per, io->mask + (size_t)b0 * io->T * io->L, y, bc, io->T, io->L, st)) return rc;
+        for (int s = 0; s < n_steps; ++s) {
+            const lsl_step &sp = steps[s];
+            const float *nz = nullptr;
+            if (sp.aw != 0.0f && noise) nz = noise + (size_t)s * total + b0 * per;
+            float *tr = trace ? trace + (size_t)s * total + b0 * per : nullptr;
+            if (int rc = run_eval(m, ws, io->x + b0 * per, nullptr, nullptr, sp.t, y != nullptr, bc, io->T, io->L, 1, sp.ax, sp.am, sp.aw, nz,
+                                  seed, (unsigned)s, elem_offset + b0 * per, tr, st))
+                return rc;
+        }
+    }
+    return 0;
+}
+
+int lsl_debug_block(lsl_model *m, int32_t bi, const float *h_in, float *h_out, const float *mods, int32_t B, int32_t T, int32_t L,
+                    void *workspace, size_t workspace_bytes, void *stream) {
+    if (!m || !m->has_weights) return fail(-2, "weights not set");
+    if (bi < 0 || bi >= 2 * m->d.depth) return fail(-3, "block index out of range");
+    const size_t need = carve(m, nullptr, B, T, L).bytes;
+    if (!workspace || workspace_bytes < need) return fail(-4, "workspace too small: need %zu bytes", need);
+    hipStream_t st = (hipStream_t)stream;
+    const Workspace ws = carve(m, (char *)workspace, B, T, L);
+    run_tables(m, ws, T, L, st);
+    const size_t bytes = (size_t)B * T * L * m->d.hidden * 4;
+    if (h_in != h_out) hipMemcpyAsync(h_out, h_in, bytes, hipMemcpyDeviceToDevice, st);
+    return run_block(m, ws, bi, h_out, mods, m->MODW, B, T, L, st);
+}
+
+int lsl_debug_mods(lsl_model *m, const float *t, const float *y, int32_t B, float *vec_out, float *mods_out, void *workspace,
+                   size_t workspace_bytes, void *stream) {
+    if (!m || !m->has_weights) return fail(-2, "weights not set");
+    const size_t need = carve(m, nullptr, B, 1, 1).bytes;
+    if (!workspace || workspace_bytes < need) return fail(-4, "workspace too small: need %zu bytes", need);
+    hipStream_t st = (hipStream_t)stream;
+    const Workspace ws = carve(m, (char *)workspace, B, 1, 1);
+    if (y) {
+        if (int rc = run_yemb(m, ws, y, B, st)) return rc;
+    }
+    return run_mods(m, ws, t, 0.0f, y ? ws.yemb : nullptr, B, vec_out, mods_out, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""Caller-side harness of the sampling path: counterpart of ``SecondStageCondLightningBase.
+{setup_conditioning, prepare_batch, sample}`` (lightning_base.py:205-263) without Lightning, plus the
+multi-GPU sharding of independent trajectories (one process per GPU, one RCCL all_gather at the end).
+
+The frozen stage-1 encoder / decoder are NOT reimplemented here: ``encode`` / ``decode`` are callables
+supplied by the caller (the reference's own first-stage model), exactly as the reference composes them.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .latent_si import LatentSIV3
+from .transport import Sampler, Transport
+
+
+@torch.no_grad()
+def setup_conditioning(latents: Tensor, cond_idx: Sequence[int], mask_cond_mean: bool) -> Tuple[Tensor, Tensor]:
+    """lightning_base.py:240-263: frames [c0, c1) are visible; hidden frames see the mean of the visible
+    ones (``mask_cond_mean``) or zeros.  Returns (x_cond, x_cond_mask int64)."""
+    B, T, L, _ = latents.shape
+    c0, c1 = int(cond_idx[0]), int(cond_idx[1])
+    mask = torch.zeros(B, T, L, dtype=torch.int64, device=latents.device)
+    mask[:, c0:c1] = 1
+    visible = mask.unsqueeze(-1).bool()
+    if mask_cond_mean:
+        fill = latents[:, c0:c1].mean(dim=1).unsqueeze(1)
+        x_cond = torch.where(visible, latents, fill)
+    else:
+        x_cond = torch.where(visible, latents, torch.zeros((), dtype=latents.dtype, device=latents.device))
+    return x_cond, mask
+
+
+def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous split of ``total`` trajectories; the first ``total % world`` ranks get one extra."""
+    q, r = divmod(total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+class SecondStageSampler:
+    """``sample(latents)``: conditioning -> noise -> fused sampler -> final latents (-> decode).
+
+    Arguments mirror the reference wrapper's hparams (second_stage/md17.py:20-37): ``cond_idx``,
+    ``mask_cond_mean``, ``sampling_method``, ``sampling_kwargs``.
+    """
+
+    def __init__(self, backbone: LatentSIV3, transport: Transport, cond_idx=(0, 10), mask_cond_mean: bool = True,
+                 sampling_method: str = "ODE", sampling_kwargs: Optional[Dict[str, Any]] = None,
+                 encode: Optional[Callable] = None, decode: Optional[Callable] = None, seed: int = 0):
+        self.backbone = backbone
+        self.si = transport
+        self.cond_idx = tuple(cond_idx)
+        self.mask_cond_mean = mask_cond_mean
+        self.sampling_method = sampling_method
+        self.sampling_kwargs = dict(sampling_kwargs or {"sampling_method": "euler", "num_steps": 10})
+        self.encode, self.decode = encode, decode
+        self.seed = seed
+        self.last_sampler: Optional[Sampler] = None
+
+    def forward(self, xt: Tensor, t: Tensor, **model_kwargs) -> Tensor:  # lightning_base.py:173-174
+        return self.backbone(x=xt, t=t, **model_kwargs)
+
+    @torch.no_grad()
+    def sample_latents(self, latents: Tensor, y: Optional[Tensor] = None, init: Optional[Tensor] = None,
+                       elem_offset: int = 0, noise: Optional[Tensor] = None) -> Tensor:
+        """latents: stage-1 latents [B,T,L,C] of the conditioning window (other frames are ignored).
+        init: optional explicit initial noise (the reference draws ``torch.randn_like(x_cond)`` on the device,
+        lightning_base.py:231; fixed-seed parity needs the tensor itself)."""
+        x_cond, mask = setup_conditioning(latents, self.cond_idx, self.mask_cond_mean)
+        if init is None:
+            g = torch.Generator(device=latents.device).manual_seed(self.seed + elem_offset)
+            init = torch.randn(x_cond.shape, generator=g, device=latents.device, dtype=x_cond.dtype)
+        sampler = Sampler(self.si, seed=self.seed)
+        sampler.elem_offset = elem_offset
+        kw = dict(self.sampling_kwargs)
+        if self.sampling_method == "SDE" and noise is not None:
+            fn = sampler.sample_sde(**{**{"sampling_method": "Euler", "diffusion_form": "linear", "diffusion_norm": 1.0,
+                                          "last_step": "Mean", "last_step_size": 0.04, "num_steps": 250}, **kw}, noise=noise)
+        else:
+            fn = sampler.get_sample_fn(self.sampling_method, kw)
+        mk = {"x_cond": x_cond, "x_cond_mask": mask}
+        if y is not None:
+            mk["y"] = y
+        out = fn(init, self.forward, **mk)[-1]
+        self.last_sampler = sampler
+        return out
+
+    @torch.no_grad()
+    def sample(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """Full counterpart of lightning_base.py:217-238; needs ``encode`` and ``decode``."""
+        if self.encode is None or self.decode is None:
+            raise RuntimeError("sample(batch) needs the frozen stage-1 encode/decode callables")
+        latents = self.encode(batch)
+        final = self.sample_latents(latents, y=batch.get("y"))
+        B = final.shape[0]
+        flat = final.reshape(B * final.shape[1], *final.shape[2:])
+        ent = batch["entities"].reshape(B * batch["entities"].shape[1], *batch["entities"].shape[2:])
+        return self.decode(flat, ent)
+
+
+@torch.no_grad()
+def sample_sharded(sample_fn: Callable[[Tensor, int], Tensor], latents: Tensor, group=None) -> Tensor:
+    """Trajectories are independent end to end (no op mixes batch elements), so the batch is split
+    contiguously over the ranks with no collective on the data path; one all_gather of the final latents
+    closes the job.  ``sample_fn(local_latents, first_global_index) -> local_final``.  Every rank gets the
+    full result in the original order.  With backend "nccl" the gather is RCCL over xGMI."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return sample_fn(latents, 0)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = latents.shape[0]
+    lo, hi = shard_bounds(B, world, rank)
+    local = sample_fn(latents[lo:hi], lo) if hi > lo else latents.new_zeros((0,) + tuple(latents.shape[1:]))
+    sizes = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
+    cap = max(sizes)
+    pad = local.new_zeros((cap,) + tuple(latents.shape[1:]))
+    pad[: hi - lo] = local
+    gathered = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(gathered, pad.contiguous(), group=group)
+    return torch.cat([g[:s] for g, s in zip(gathered, sizes)], dim=0)

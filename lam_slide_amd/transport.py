@@ -1,0 +1,432 @@
+"""``CreateTransport`` / ``Transport`` / ``Sampler``: drop-in for ``src.modules.transport`` on the sampling
+side (``configs/model/*/second-stage.yaml`` ``transport:`` blocks, lightning_base.py:219-234).
+
+``Sampler(transport).get_sample_fn(method, kwargs)`` returns ``fn(init, model, **model_kwargs)`` exactly like
+the reference (transport.py:475-503).  When ``model`` resolves to a :class:`lam_slide_amd.LatentSIV3`
+(the module itself, its bound ``forward``, or a bound method of an object whose ``.backbone`` is one, which is
+what ``SecondStageCondLightningBase.forward`` is) and the solver is fixed-grid Euler / Euler-Maruyama, the
+whole loop runs inside liblamslide_hip.so (``lsl_sample``): every step is the affine update
+``x <- ax x + am net(x,t) + aw w`` with (ax, am, aw) derived here in float64 from the reference's formulas.
+Any other callable or solver goes through the generic per-step loop below, which mirrors
+integrators.py:7-120 and calls ``model`` once per drift evaluation.
+
+Preserved semantics: ``num_steps=N`` means N-1 Euler updates on ``linspace(t0, t1, N)``; the SDE result has
+``len == num_steps``; (t0, t1) come from ``check_interval`` (transport.py:69-101); errors are the reference's
+(KeyError unknown path, NotImplementedError unknown sampler / diffusion form / last step, AssertionError t0<t1).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import math
+from collections.abc import Sequence
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .latent_si import LatentSIV3
+
+
+class ModelType(enum.Enum):
+    NOISE = enum.auto()
+    SCORE = enum.auto()
+    VELOCITY = enum.auto()
+    DATA = enum.auto()
+
+
+class PathType(enum.Enum):
+    LINEAR = enum.auto()
+    GVP = enum.auto()
+    VP = enum.auto()
+
+
+class WeightType(enum.Enum):
+    NONE = enum.auto()
+    VELOCITY = enum.auto()
+    LIKELIHOOD = enum.auto()
+
+
+_SMIN, _SMAX = 0.1, 20.0
+
+
+class _Schedule:
+    """Scalar (float64) alpha/sigma schedule of one path type: path.py:21-206 evaluated at one t."""
+
+    def __init__(self, path_type: PathType):
+        self.kind = path_type
+
+    def alpha(self, t: float) -> Tuple[float, float]:
+        if self.kind is PathType.LINEAR:
+            return t, 1.0
+        if self.kind is PathType.GVP:
+            return math.sin(t * math.pi / 2), math.pi / 2 * math.cos(t * math.pi / 2)
+        a = math.exp(self._lm(t))
+        return a, a * self._dlm(t)
+
+    def sigma(self, t: float) -> Tuple[float, float]:
+        if self.kind is PathType.LINEAR:
+            return 1 - t, -1.0
+        if self.kind is PathType.GVP:
+            return math.cos(t * math.pi / 2), -math.pi / 2 * math.sin(t * math.pi / 2)
+        p = 2 * self._lm(t)
+        s = math.sqrt(1 - math.exp(p))
+        return s, math.exp(p) * (2 * self._dlm(t)) / (-2 * s)
+
+    def _lm(self, t):
+        return -0.25 * ((1 - t) ** 2) * (_SMAX - _SMIN) - 0.5 * (1 - t) * _SMIN
+
+    def _dlm(self, t):
+        return 0.5 * (1 - t) * (_SMAX - _SMIN) + 0.5 * _SMIN
+
+    def drift_terms(self, t: float) -> Tuple[float, float]:
+        """(k, var): the reference's compute_drift returns (-k x ... ) i.e. drift_mean = k * x, drift_var = var."""
+        if self.kind is PathType.VP:
+            beta = _SMIN + (1 - t) * (_SMAX - _SMIN)
+            return -0.5 * beta, beta / 2
+        if self.kind is PathType.LINEAR:
+            ratio = 1 / t if t != 0 else math.inf  # torch gives inf here too (Linear path evaluated at t0 = 0)
+        else:
+            ratio = math.pi / (2 * math.tan(t * math.pi / 2))
+        s, ds = self.sigma(t)
+        return -ratio, ratio * s * s - s * ds
+
+    def diffusion(self, t: float, form: str, norm: float) -> float:
+        if form == "constant":
+            return norm
+        if form == "SBDM":
+            return norm * self.drift_terms(t)[1]
+        if form == "sigma":
+            return norm * self.sigma(t)[0]
+        if form == "linear":
+            return norm * (1 - t)
+        if form == "decreasing":
+            return 0.25 * (norm * math.cos(math.pi * t) + 1) ** 2
+        if form == "inccreasing-decreasing":
+            return norm * math.sin(math.pi * t) ** 2
+        raise NotImplementedError(f"Diffusion form {form} not implemented")
+
+
+class Transport:
+    def __init__(self, *, model_type, path_type, loss_type, train_eps, sample_eps):
+        self.loss_type = loss_type
+        self.model_type = model_type
+        self.path_type = path_type
+        self.schedule = _Schedule(path_type)
+        self.train_eps = train_eps
+        self.sample_eps = sample_eps
+
+    def check_interval(self, train_eps, sample_eps, *, diffusion_form="SBDM", sde=False, reverse=False, eval=False,
+                       last_step_size=0.0):
+        t0, t1 = 0, 1
+        eps = train_eps if not eval else sample_eps
+        if self.path_type is PathType.VP:
+            t1 = 1 - eps if (not sde or last_step_size == 0) else 1 - last_step_size
+        elif self.model_type != ModelType.VELOCITY or sde:
+            t0 = eps if (diffusion_form == "SBDM" and sde) or self.model_type != ModelType.VELOCITY else 0
+            t1 = 1 - eps if (not sde or last_step_size == 0) else 1 - last_step_size
+        if reverse:
+            t0, t1 = 1 - t0, 1 - t1
+        return t0, t1
+
+    # velocity(x, m) = vx * x + vm * m and score(x, m) = sx * x + sm * m for network output m (transport.py:158-226)
+    def velocity_coeffs(self, t: float) -> Tuple[float, float]:
+        if self.model_type is ModelType.VELOCITY:
+            return 0.0, 1.0
+        k, var = self.schedule.drift_terms(t)  # v = -drift_mean + var * score, drift_mean = k * x
+        sx, sm = self.score_coeffs(t)
+        return -k + var * sx, var * sm
+
+    def score_coeffs(self, t: float) -> Tuple[float, float]:
+        sch = self.schedule
+        if self.model_type is ModelType.SCORE:
+            return 0.0, 1.0
+        if self.model_type is ModelType.NOISE:
+            return 0.0, -1.0 / sch.sigma(t)[0]
+        if self.model_type is ModelType.DATA:
+            s, _ = sch.sigma(t)
+            a, _ = sch.alpha(t)
+            return -1.0 / (s * s), a / (s * s)
+        a, da = sch.alpha(t)
+        s, ds = sch.sigma(t)
+        rev = a / da
+        var = s * s - rev * ds * s
+        return -1.0 / var, rev / var
+
+
+class CreateTransport:
+    """Same keywords as the reference factory (transport/__init__.py:7-77); call it to get the Transport."""
+
+    def __init__(self, path_type="Linear", prediction="velocity", loss_weight=None, train_eps=None, sample_eps=None):
+        self.path_type = path_type
+        self.prediction = prediction
+        self.loss_weight = loss_weight
+        self.train_eps = train_eps
+        self.sample_eps = sample_eps
+
+    def __call__(self) -> Transport:
+        model_type = {"noise": ModelType.NOISE, "score": ModelType.SCORE, "data": ModelType.DATA}.get(self.prediction, ModelType.VELOCITY)
+        loss_type = {"velocity": WeightType.VELOCITY, "likelihood": WeightType.LIKELIHOOD}.get(self.loss_weight, WeightType.NONE)
+        path_type = {"Linear": PathType.LINEAR, "GVP": PathType.GVP, "VP": PathType.VP}[self.path_type]  # KeyError as the reference
+        if path_type is PathType.VP:
+            train_eps = 1e-5 if self.train_eps is None else self.train_eps
+            sample_eps = 1e-3 if self.sample_eps is None else self.sample_eps
+        elif model_type != ModelType.VELOCITY:
+            train_eps = 1e-3 if self.train_eps is None else self.train_eps
+            sample_eps = 1e-3 if self.sample_eps is None else self.sample_eps
+        else:
+            train_eps = 0
+            sample_eps = 0
+        return Transport(model_type=model_type, path_type=path_type, loss_type=loss_type, train_eps=train_eps, sample_eps=sample_eps)
+
+
+class SampleResult(Sequence):
+    """What the fused samplers return: indexable like the reference's stacked tensor / list of states.
+    ``[-1]`` (the only element the reference's callers read, lightning_base.py:230-234) is always there;
+    earlier states only when the sampler was built with ``keep_trajectory=True``."""
+
+    def __init__(self, final: Tensor, n: int, trace: Optional[Tensor] = None, first: Optional[Tensor] = None, offset: int = 0):
+        self.final, self.n, self.trace, self.first, self.offset = final, n, trace, first, offset
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self.n))]
+        if i < 0:
+            i += self.n
+        if i == self.n - 1:
+            return self.final
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        if self.trace is None:
+            raise IndexError("intermediate states were not kept: build the sampler with keep_trajectory=True")
+        if self.offset and i == 0:
+            return self.first
+        return self.trace[i - self.offset]
+
+
+def resolve_backbone(model: Callable) -> Optional[LatentSIV3]:
+    if isinstance(model, LatentSIV3):
+        return model
+    tagged = getattr(model, "lsl_backbone", None)
+    if isinstance(tagged, LatentSIV3):
+        return tagged
+    owner = getattr(model, "__self__", None)
+    if isinstance(owner, LatentSIV3) and getattr(model, "__name__", "") in ("forward", "__call__"):
+        return owner
+    if owner is not None and getattr(model, "__name__", "") == "forward" and isinstance(getattr(owner, "backbone", None), LatentSIV3):
+        return owner.backbone  # LightningModule.forward == backbone(x=xt, t=t, **kw) (lightning_base.py:173-174)
+    return None
+
+
+def _f32(v: float) -> float:
+    return float(torch.tensor(v, dtype=torch.float32))
+
+
+class Sampler:
+    def __init__(self, transport: Transport, fused: Optional[bool] = None, keep_trajectory: bool = False, seed: int = 0):
+        self.transport = transport
+        self.fused = fused
+        self.keep_trajectory = keep_trajectory
+        self.seed = seed
+        self.last_path: Optional[str] = None
+        self.elem_offset = 0  # global element index of this rank's first state element (device noise stream)
+
+    # ---- step tables ------------------------------------------------------------------------------------
+    def ode_steps(self, num_steps: int, reverse: bool = False) -> Tuple[List[Tuple[float, float, float, float]], Tensor]:
+        tr = self.transport
+        t0, t1 = tr.check_interval(tr.train_eps, tr.sample_eps, sde=False, eval=True, reverse=reverse, last_step_size=0.0)
+        assert t0 < t1, "ODE sampler has to be in forward time"
+        grid = torch.linspace(t0, t1, num_steps)
+        steps = []
+        for i in range(num_steps - 1):
+            ti = float(grid[i])
+            dt = float(grid[i + 1] - grid[i])  # fp32 difference, as torchdiffeq's fixed grid forms it
+            te = _f32(1 - ti) if reverse else ti
+            vx, vm = tr.velocity_coeffs(te)
+            steps.append((te, 1.0 + dt * vx, dt * vm, 0.0))
+        return steps, grid
+
+    def sde_steps(self, *, diffusion_form, diffusion_norm, last_step, last_step_size, num_steps):
+        tr = self.transport
+        if last_step is None:
+            last_step_size = 0.0
+        t0, t1 = tr.check_interval(tr.train_eps, tr.sample_eps, diffusion_form=diffusion_form, sde=True, eval=True, reverse=False,
+                                   last_step_size=last_step_size)
+        assert t0 < t1, "SDE sampler has to be in forward time"
+        grid = torch.linspace(t0, t1, num_steps)
+        dt = float(grid[1] - grid[0])
+        sch = tr.schedule
+
+        def drift(t):
+            vx, vm = tr.velocity_coeffs(t)
+            sx, sm = tr.score_coeffs(t)
+            g = sch.diffusion(t, diffusion_form, diffusion_norm)
+            return vx + g * sx, vm + g * sm, g
+
+        steps = []
+        for i in range(num_steps - 1):
+            ti = float(grid[i])
+            dx, dm, g = drift(ti)
+            steps.append((ti, 1.0 + dt * dx, dt * dm, math.sqrt(2 * g) * math.sqrt(dt)))
+        t1f = _f32(t1)
+        if last_step is None:
+            pass
+        elif last_step == "Mean":
+            dx, dm, _ = drift(t1f)
+            steps.append((t1f, 1.0 + last_step_size * dx, last_step_size * dm, 0.0))
+        elif last_step == "Euler":
+            vx, vm = tr.velocity_coeffs(t1f)
+            steps.append((t1f, 1.0 + last_step_size * vx, last_step_size * vm, 0.0))
+        elif last_step == "Tweedie":
+            a = sch.alpha(t1f)[0]
+            s = sch.sigma(t1f)[0]
+            sx, sm = tr.score_coeffs(t1f)
+            steps.append((t1f, 1.0 / a + s * s / a * sx, s * s / a * sm, 0.0))
+        else:
+            raise NotImplementedError()
+        return steps, grid
+
+    # ---- fused execution ----------------------------------------------------------------------------------
+    def run_fused(self, net: LatentSIV3, init: Tensor, steps, n_result: int, model_kwargs: Dict[str, Any],
+                  noise: Optional[Tensor] = None, duplicate_last: bool = False) -> SampleResult:
+        extra = set(model_kwargs) - {"x_cond", "x_cond_mask", "y"}
+        if extra:
+            raise TypeError(f"unexpected model kwargs {sorted(extra)}")
+        net._require_gpu(init)
+        lib = _lib.load()
+        net.ensure_packed(init.device)
+        x = init.detach().float().contiguous().clone()
+        io, keep = net.make_io(x, model_kwargs["x_cond"], model_kwargs["x_cond_mask"], model_kwargs.get("y"))
+        ws = net.workspace(io.B, io.T, io.L, init.device)
+        arr = (_lib.Step * len(steps))(*[_lib.Step(*s) for s in steps])
+        trace = None
+        if self.keep_trajectory:
+            trace = torch.empty((len(steps),) + tuple(x.shape), dtype=torch.float32, device=x.device)
+        nz = None
+        if noise is not None:  # slice s belongs to step s, like the reference's one draw per EM step
+            nz = noise.detach().float().contiguous().to(x.device)
+            need = max([i + 1 for i, s in enumerate(steps) if s[3] != 0.0], default=0)
+            if nz.shape[0] < need or tuple(nz.shape[1:]) != tuple(x.shape):
+                raise ValueError(f"noise must be [>={need}, {tuple(x.shape)}], got {tuple(nz.shape)}")
+        stream = torch.cuda.current_stream(init.device).cuda_stream
+        _lib.check(lib.lsl_sample(net._handle, C.byref(io), arr, len(steps), nz.data_ptr() if nz is not None else None,
+                                  nz.shape[0] if nz is not None else 0, self.seed, self.elem_offset, trace.data_ptr() if trace is not None else None, ws.data_ptr(),
+                                  ws.numel(), stream))
+        net.last_path = "hip"
+        self.last_path = "fused"
+        del keep
+        x = x.to(init.dtype)
+        if trace is None:
+            return SampleResult(x, n_result)
+        if duplicate_last:  # last_step=None: the reference appends xs[-1] again (transport.py:353-357)
+            trace = torch.cat([trace, trace[-1:]], dim=0)
+            return SampleResult(x, n_result, trace, None, 0)
+        if n_result == len(steps) + 1:  # ODE: state 0 is the initial noise
+            return SampleResult(x, n_result, trace, init, 1)
+        return SampleResult(x, n_result, trace, None, 0)
+
+    # ---- generic execution (any callable; mirrors integrators.py) -------------------------------------------
+    def _vel(self, x, t, model, **kw):
+        tr = self.transport
+        out = model(x, t, **kw)
+        tf = float(t.flatten()[0])
+        vx, vm = tr.velocity_coeffs(tf)
+        v = vx * x + vm * out
+        assert v.shape == x.shape, "Output shape from ODE solver must match input shape"
+        return v, out
+
+    def _sde_drift(self, x, t, model, form, norm, **kw):
+        tr = self.transport
+        v, out = self._vel(x, t, model, **kw)
+        tf = float(t.flatten()[0])
+        sx, sm = tr.score_coeffs(tf)
+        g = tr.schedule.diffusion(tf, form, norm)
+        return v + g * (sx * x + sm * out), g
+
+    # ---- reference API --------------------------------------------------------------------------------------
+    def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False):
+        if sampling_method != "euler":
+            raise NotImplementedError(f"ODE solver {sampling_method!r}: only torchdiffeq's fixed-grid 'euler' is implemented "
+                                      "(dopri5 / adaptive solvers are out of scope, SURVEY.md 8c)")
+        steps, grid = self.ode_steps(num_steps, reverse)
+
+        def _sample(init, model, **model_kwargs):
+            net = resolve_backbone(model) if self.fused is not False else None
+            if net is not None and init.is_cuda:
+                return self.run_fused(net, init, steps, num_steps, model_kwargs)
+            if self.fused:
+                raise RuntimeError("fused sampling requested but the model is not a lam_slide_amd.LatentSIV3 on a GPU")
+            self.last_path = "generic"
+            x = init
+            xs = [x]
+            for (te, _, _, _), i in zip(steps, range(num_steps - 1)):
+                tv = torch.ones(x.size(0), device=x.device) * te
+                v, _ = self._vel(x, tv, model, **model_kwargs)
+                x = x + (grid[i + 1] - grid[i]).to(x.device) * v
+                xs.append(x)
+            return torch.stack(xs)
+
+        return _sample
+
+    def sample_sde(self, *, sampling_method="Euler", diffusion_form="SBDM", diffusion_norm=1.0, last_step="Mean",
+                   last_step_size=0.04, num_steps=250, noise: Optional[Tensor] = None):
+        if sampling_method not in ("Euler", "Heun"):
+            raise NotImplementedError("Smapler type not implemented.")
+        if last_step not in (None, "Mean", "Tweedie", "Euler"):
+            raise NotImplementedError()
+        steps, grid = self.sde_steps(diffusion_form=diffusion_form, diffusion_norm=diffusion_norm, last_step=last_step,
+                                     last_step_size=last_step_size, num_steps=num_steps)
+        dt = grid[1] - grid[0]
+
+        def _sample(init, model, **model_kwargs):
+            net = resolve_backbone(model) if self.fused is not False else None
+            if net is not None and init.is_cuda and sampling_method == "Euler":
+                return self.run_fused(net, init, steps, num_steps, model_kwargs, noise=noise, duplicate_last=last_step is None)
+            if self.fused:
+                raise RuntimeError("fused sampling requested but unavailable for this model / solver")
+            self.last_path = "generic"
+            x = init
+            xs = []
+            for i in range(num_steps - 1):
+                ti = grid[i]
+                w = noise[i].to(x) if noise is not None else torch.randn(x.size()).to(x)
+                dw = w * torch.sqrt(dt).to(x)
+                tv = torch.ones(x.size(0)).to(x) * ti.to(x)
+                if sampling_method == "Euler":
+                    d, g = self._sde_drift(x, tv, model, diffusion_form, diffusion_norm, **model_kwargs)
+                    x = x + d * dt.to(x) + math.sqrt(2 * g) * dw
+                else:
+                    g = self.transport.schedule.diffusion(float(ti), diffusion_form, diffusion_norm)
+                    xhat = x + math.sqrt(2 * g) * dw
+                    k1, _ = self._sde_drift(xhat, tv, model, diffusion_form, diffusion_norm, **model_kwargs)
+                    xp = xhat + dt.to(x) * k1
+                    k2, _ = self._sde_drift(xp, tv + dt.to(x), model, diffusion_form, diffusion_norm, **model_kwargs)
+                    x = xhat + 0.5 * dt.to(x) * (k1 + k2)
+                xs.append(x)
+            if last_step is None:
+                xs.append(xs[-1])
+            else:
+                te, ax, am, _ = steps[-1]
+                tv = torch.ones(init.size(0), device=x.device) * te
+                out = model(xs[-1], tv, **model_kwargs)
+                xs.append(ax * xs[-1] + am * out)
+            assert len(xs) == num_steps, "Samples does not match the number of steps"
+            return xs
+
+        return _sample
+
+    def get_sample_fn(self, sampling_method: str = "ODE", sampling_kwargs: Dict[str, Any] = {}):
+        sde_kwargs = {"sampling_method": "Euler", "diffusion_form": "linear", "diffusion_norm": 1.0, "last_step": "Mean",
+                      "last_step_size": 0.04, "num_steps": 250}
+        ode_kwargs = {"sampling_method": "dopri5", "num_steps": 50, "atol": 1e-6, "rtol": 1e-3, "reverse": False}
+        if sampling_method == "SDE":
+            sde_kwargs.update(sampling_kwargs)
+            return self.sample_sde(**sde_kwargs)
+        if sampling_method == "ODE":
+            ode_kwargs.update(sampling_kwargs)
+            return self.sample_ode(**ode_kwargs)
+        return None

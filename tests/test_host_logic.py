@@ -1,0 +1,213 @@
+"""CPU tests of the host side: weight packing, the affine step tables the fused sampler consumes, the generic
+sampler loop, the C-ABI surface (load + symbols + argument validation, no compute), and the 2-rank sharding
+over gloo."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, rel_l2
+from oracle import harness, latent_net, transport as otr
+
+
+def test_library_builds_and_exports_header_symbols():
+    import __graft_entry__ as ge
+    ge.build()
+    from lam_slide_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "lsl_api.h")).read()
+    declared = set(re.findall(r"\b(lsl_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTED), declared ^ set(_lib.EXPORTED)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_model_create_validation_without_gpu():
+    from lam_slide_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    ok = _lib.ModelDesc(32, 256, 16, 16, 16, 512, 4, 0, 0, 10000.0)
+    assert lib.lsl_model_create(C.byref(ok), C.byref(h)) == 0
+    assert lib.lsl_workspace_bytes(h, 4, 30, 192) > 0
+    io = _lib.IO(None, None, None, None, None, None, 1, 1, 1)
+    assert lib.lsl_forward(h, C.byref(io), None, 0, None) == -2  # weights not set: refuses before touching the GPU
+    assert b"weights" in lib.lsl_last_error()
+    lib.lsl_model_destroy(h)
+    bad = _lib.ModelDesc(32, 250, 16, 15, 16, 512, 4, 0, 0, 10000.0)
+    assert lib.lsl_model_create(C.byref(bad), C.byref(h)) == -20
+    assert b"divisible" in lib.lsl_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(-20)
+
+
+def test_module_state_dict_contract_and_errors():
+    from lam_slide_amd import LatentSIV3
+    for kw in (dict(depth=2, in_dim=8, hidden_size=64, num_heads=4, vec_in_dim=16), dict(depth=3, in_dim=32, hidden_size=128, num_heads=4, share_weights=True),
+               dict(depth=1, in_dim=96, hidden_size=384, num_heads=16, mlp_ratio=4)):
+        net = LatentSIV3(reset_parameters=False, **kw)
+        sh = latent_net.NetShape(**kw)
+        ref = latent_net.random_params(sh, seed=0)
+        sd = net.state_dict()
+        assert set(sd) == set(ref)
+        assert all(sd[k].shape == ref[k].shape for k in ref)
+        net.load_state_dict({"_orig_mod." + k if False else k: v for k, v in ref.items()})
+    z = LatentSIV3(depth=1, in_dim=8, hidden_size=64, num_heads=4)  # reset_parameters=True: AdaLN-Zero init
+    assert float(z.blocks[0].modulation.lin.weight.detach().abs().sum()) == 0 and float(z.linear.weight.detach().abs().sum()) == 0
+    with pytest.raises(ValueError):
+        LatentSIV3(depth=1, in_dim=8, hidden_size=66, num_heads=4)
+    with pytest.raises(RuntimeError):  # no CPU fallback
+        z(torch.zeros(1, 2, 3, 8), torch.zeros(1), torch.zeros(1, 2, 3, 8), torch.zeros(1, 2, 3, dtype=torch.long))
+
+
+@pytest.mark.parametrize("hidden,heads,mlp", [(64, 4, 2), (192, 8, 1), (128, 4, 2), (384, 16, 4)])
+def test_packing_preserves_the_linear_maps(hidden, heads, mlp):
+    """Packed (padded, reordered, bf16) weights must compute the same block as the originals: run the
+    oracle block with weights unpacked from the packed tensors."""
+    from lam_slide_amd.packing import make_dims, pack_block
+    sh = latent_net.NetShape(depth=1, in_dim=8, hidden_size=hidden, num_heads=heads, mlp_ratio=mlp)
+    p = latent_net.random_params(sh, seed=1)
+    dm = make_dims(1, 8, hidden, heads, mlp, None, False, 10000)
+    pk = pack_block(p, "blocks.0.spatial_block", dm, "cpu")
+    H, hd, hdp, D, M = heads, hidden // heads, dm.head_dim_pad, hidden, sh.mlp_dim
+    assert pk["w1"].shape == (dm.f1, D) and pk["w2"].shape == (D, dm.k2) and dm.k2 % 64 == 0 and dm.hhd % 32 == 0
+    w1 = pk["w1"].float()
+    rows = torch.cat([w1[s * dm.hhd:(s + 1) * dm.hhd].view(H, hdp, D)[:, :hd].reshape(H * hd, D) for s in range(3)] + [w1[3 * dm.hhd:3 * dm.hhd + M]])
+    assert torch.equal(rows, p["blocks.0.spatial_block.linear1.weight"].to(torch.bfloat16).float())
+    pad = w1[: dm.hhd].view(H, hdp, D)[:, hd:]
+    assert float(pad.abs().sum()) == 0
+    w2 = pk["w2"].float()
+    cols = torch.cat([w2[:, : dm.hhd].view(D, H, hdp)[:, :, :hd].reshape(D, H * hd), w2[:, dm.hhd:dm.hhd + M]], dim=1)
+    assert torch.equal(cols, p["blocks.0.spatial_block.linear2.weight"].to(torch.bfloat16).float())
+    assert torch.equal(pk["qs"][:hd], p["blocks.0.spatial_block.norm.query_norm.scale"]) and float(pk["qs"][hd:].abs().sum()) == 0
+
+
+def _toy_model(x, t, **kw):
+    return torch.tanh(x) * 0.7 + 0.1 * t.view(-1, 1, 1, 1).to(x.dtype)
+
+
+@pytest.mark.parametrize("path", otr.PATHS)
+@pytest.mark.parametrize("pred", otr.PREDICTIONS)
+def test_affine_step_tables_reproduce_the_oracle_ode(path, pred):
+    """x <- ax x + am m with the float64-derived coefficients must equal the reference arithmetic."""
+    from lam_slide_amd import CreateTransport, Sampler
+    g = torch.Generator().manual_seed(0)
+    init = torch.randn(2, 3, 4, 5, generator=g, dtype=torch.float64)
+    want = otr.sample_ode(otr.Transport(path, pred), init, _toy_model, num_steps=9)[-1]
+    s = Sampler(CreateTransport(path, pred)())
+    steps, grid = s.ode_steps(9)
+    x = init.clone()
+    for te, ax, am, aw in steps:
+        assert aw == 0.0
+        x = ax * x + am * _toy_model(x, torch.ones(2) * te)
+    assert rel_l2(x, want) < 1e-5  # the oracle (like the reference) evaluates sin/cos(t) in fp32
+    got = s.get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": 9})(init, _toy_model)
+    assert s.last_path == "generic" and got.shape[0] == 9
+    assert rel_l2(got[-1], want) < 1e-5
+
+
+@pytest.mark.parametrize("form,last", [("linear", "Mean"), ("SBDM", None), ("sigma", "Euler"), ("decreasing", "Tweedie"), ("inccreasing-decreasing", "Mean")])
+@pytest.mark.parametrize("path,pred", [("GVP", "data"), ("Linear", "velocity"), ("VP", "noise"), ("Linear", "score")])
+def test_affine_step_tables_reproduce_the_oracle_sde(form, last, path, pred):
+    from lam_slide_amd import CreateTransport, Sampler
+    g = torch.Generator().manual_seed(1)
+    init = torch.randn(2, 3, 4, 5, generator=g, dtype=torch.float64)
+    n = 7
+    noise = [torch.randn(2, 3, 4, 5, generator=g, dtype=torch.float64) for _ in range(n - 1)]
+    want = otr.sample_sde(otr.Transport(path, pred), init, _toy_model, noise=noise, diffusion_form=form, last_step=last, num_steps=n)
+    if not torch.isfinite(want[-1]).all():
+        pytest.skip("degenerate in the reference too: Linear path + SBDM diffusion divides by t0 = 0")
+    s = Sampler(CreateTransport(path, pred)())
+    steps, _ = s.sde_steps(diffusion_form=form, diffusion_norm=1.0, last_step=last, last_step_size=0.04, num_steps=n)
+    x = init.clone()
+    for i, (te, ax, am, aw) in enumerate(steps):
+        m = _toy_model(x, torch.ones(2) * te)
+        x = ax * x + am * m + (aw * noise[i] if aw != 0.0 else 0.0)  # noise slice i belongs to step i
+    assert rel_l2(x, want[-1]) < 1e-5
+    got = s.sample_sde(diffusion_form=form, last_step=last, num_steps=n, noise=torch.stack(noise))(init, _toy_model)
+    assert len(got) == n and rel_l2(got[-1], want[-1]) < 1e-5
+    heun_w = otr.sample_sde(otr.Transport(path, pred), init, _toy_model, noise=noise, sampling_method="Heun", diffusion_form=form, last_step=last, num_steps=n)
+    heun_g = s.sample_sde(sampling_method="Heun", diffusion_form=form, last_step=last, num_steps=n, noise=torch.stack(noise))(init, _toy_model)
+    assert rel_l2(heun_g[-1], heun_w[-1]) < 1e-5
+
+
+def test_intervals_and_defaults_match_golden(golden):
+    from lam_slide_amd import CreateTransport
+    f = golden("f3_transport.npz")
+    for path in otr.PATHS:
+        for pred in otr.PREDICTIONS:
+            tr = CreateTransport(path, pred)()
+            iv = []
+            for sde in (False, True):
+                for form in ("SBDM", "linear"):
+                    for ls in (0.0, 0.04):
+                        iv.append(list(map(float, tr.check_interval(tr.train_eps, tr.sample_eps, diffusion_form=form, sde=sde, eval=True, last_step_size=ls))))
+            assert torch.equal(torch.tensor(iv, dtype=torch.float64), f.group(f"{path}.{pred}")["intervals"])
+            # scalar coefficient functions against the reference's tensors on the fixture's t grid
+            x, mo, t = f["x"], f["model_out"], f["t"]
+            v = torch.stack([tr.velocity_coeffs(float(ti))[0] * x[i] + tr.velocity_coeffs(float(ti))[1] * mo[i] for i, ti in enumerate(t)])
+            s = torch.stack([tr.score_coeffs(float(ti))[0] * x[i] + tr.score_coeffs(float(ti))[1] * mo[i] for i, ti in enumerate(t)])
+            assert rel_l2(v, f.group(f"{path}.{pred}")["velocity"]) < 1e-5
+            assert rel_l2(s, f.group(f"{path}.{pred}")["score"]) < 1e-5
+
+
+def test_setup_conditioning_bit_exact(golden):
+    from lam_slide_amd import setup_conditioning
+    f = golden("f5_cond.npz")
+    for mean in (True, False):
+        for ci in ((0, 3), (0, 1), (2, 5)):
+            xc, mask = setup_conditioning(f["latents"], ci, mean)
+            assert torch.equal(xc, f[f"m{int(mean)}.{ci[0]}_{ci[1]}.x_cond"]) and torch.equal(mask, f[f"m{int(mean)}.{ci[0]}_{ci[1]}.mask"])
+
+
+def test_shard_bounds_cover_and_order():
+    from lam_slide_amd import shard_bounds
+    for total in (0, 1, 7, 8, 8192, 8193):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["LSL_ROOT"])
+from lam_slide_amd import sample_sharded
+from oracle import harness, latent_net, transport as otr
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["PORT"], rank=int(os.environ["RANK"]), world_size=2)
+sh = latent_net.NetShape(depth=1, in_dim=8, hidden_size=64, num_heads=4)
+p = latent_net.random_params(sh, seed=0)
+g = torch.Generator().manual_seed(0)
+lat = torch.randn(5, 4, 6, 8, generator=g)
+init = torch.randn(5, 4, 6, 8, generator=g)
+def local(l, lo):
+    xc, m = harness.setup_conditioning(l, (0, 2), True)
+    return harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init[lo:lo + l.shape[0]], xc, m, None, "ODE", {"sampling_method": "euler", "num_steps": 4})
+out = sample_sharded(local, lat)
+full = local(lat, 0)
+assert out.shape == full.shape and torch.allclose(out, full, atol=1e-6), float((out - full).abs().max())
+dist.destroy_process_group()
+print("rank", os.environ["RANK"], "ok")
+"""
+
+
+def test_two_rank_sharding_over_gloo(tmp_path):
+    """N>1 path on CPU: contiguous batch split, no data-path collective, one all_gather; the CPU oracle
+    stands in for the per-rank compute (checker role only)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=str(port), LSL_ROOT=ROOT, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
