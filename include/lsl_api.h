@@ -111,6 +111,9 @@ void lsl_model_destroy(lsl_model *m);
 /* Trajectories processed per pass (cache-residency knob); 0 = library default. */
 int lsl_model_set_chunk(lsl_model *m, int32_t trajectories_per_pass);
 
+/* Trajectories the library processes per pass for a call of this size (<= B). */
+int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L);
+
 /* Bytes of caller-provided device scratch needed for a call with these sizes. */
 size_t lsl_workspace_bytes(const lsl_model *m, int32_t B, int32_t T, int32_t L);
 
@@ -134,6 +137,13 @@ int lsl_debug_block(lsl_model *m, int32_t block_index /* 0..2*depth-1 */, const 
                     void *workspace, size_t workspace_bytes, void *stream);
 int lsl_debug_mods(lsl_model *m, const float *t, const float *y, int32_t B, float *vec_out, float *mods_out,
                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Measurement hooks (bench.py roofline leg): bracket every launch of one kernel class with HIP events on
+ * the stream it is launched on.  kernel: 0 linear1 GEMM, 1 linear2 GEMM, 2 attention, 3 LayerNorm+modulate,
+ * 4 output head + state update, 5 input embedding, 6 modulation tables; -1 disables.
+ * lsl_profile_read synchronises on the recorded events and returns their summed duration. */
+int lsl_profile_enable(lsl_model *m, int32_t kernel, int32_t max_launches);
+int lsl_profile_read(lsl_model *m, double *total_ms, int32_t *launches);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,8 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTED = (
     "lsl_version", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
-    "lsl_model_set_chunk", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_debug_block", "lsl_debug_mods",
+    "lsl_model_set_chunk", "lsl_pass_size", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_debug_block", "lsl_debug_mods",
+    "lsl_profile_enable", "lsl_profile_read",
 )
 
 
@@ -83,6 +84,7 @@ def load() -> C.CDLL:
     lib.lsl_model_destroy.argtypes = [C.c_void_p]
     lib.lsl_model_destroy.restype = None
     lib.lsl_model_set_chunk.argtypes = [C.c_void_p, C.c_int32]
+    lib.lsl_pass_size.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.lsl_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.lsl_workspace_bytes.restype = C.c_size_t
     lib.lsl_forward.argtypes = [C.c_void_p, C.POINTER(IO), C.c_void_p, C.c_size_t, C.c_void_p]
@@ -92,6 +94,8 @@ def load() -> C.CDLL:
                                     C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_debug_mods.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]
+    lib.lsl_profile_enable.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.lsl_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     if lib.lsl_version() != 1:
         raise RuntimeError("liblamslide_hip.so version mismatch")
     _lib = lib

@@ -38,7 +38,24 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+struct Profiler {
+    int kernel = -1, cap = 0, used = 0;
+    std::vector<hipEvent_t> ev;  // 2 per launch
+    void begin(int k, hipStream_t st) {
+        if (k == kernel && used < cap) hipEventRecord(ev[2 * used], st);
+    }
+    void end(int k, hipStream_t st) {
+        if (k == kernel && used < cap) hipEventRecord(ev[2 * used++ + 1], st);
+    }
+    void clear() {
+        for (auto e : ev) hipEventDestroy(e);
+        ev.clear();
+        kernel = -1; cap = used = 0;
+    }
+};
+
 struct lsl_model {
+    Profiler prof;
     lsl_model_desc d;
     lsl_weights w;
     std::vector<lsl_block_weights> blocks;
@@ -182,10 +199,11 @@ void launch_attention_t(const AttnArgs &a, hipStream_t st) {
 
 // conditioning vector -> all modulation tables for `rows` trajectories (latent_si_v31.py:176-178,
 // mmdit.py:184-197).  t_dev == nullptr: scalar t.  yemb == nullptr: no class conditioning.
-int run_mods(const lsl_model *m, const Workspace &ws, const float *t_dev, float t_scalar, const float *yemb, int rows,
+int run_mods(lsl_model *m, const Workspace &ws, const float *t_dev, float t_scalar, const float *yemb, int rows,
              float *vec_out, float *mods_out, hipStream_t st) {
     const lsl_weights &w = m->w;
     const int D = m->d.hidden;
+    m->prof.begin(6, st);
     hipLaunchKernelGGL(k_time_features, dim3((rows * 128 + 255) / 256), dim3(256), 0, st, ws.tfeat, t_dev, t_scalar, w.time_freqs, rows);
     hipLaunchKernelGGL((k_dense_rows<false, true>), dim3((D + 3) / 4), dim3(256), 0, st, ws.hid, ws.tfeat, w.time_w1, w.time_b1,
                        (const float *)nullptr, rows, 256, D, 0);
@@ -193,12 +211,13 @@ int run_mods(const lsl_model *m, const Workspace &ws, const float *t_dev, float 
                        rows, D, D, D);
     hipLaunchKernelGGL((k_dense_rows<true, false>), dim3((m->MODW + 3) / 4), dim3(256), 0, st, mods_out, vec_out, w.mod_w, w.mod_b,
                        (const float *)nullptr, rows, D, m->MODW, 0);
+    m->prof.end(6, st);
     LSL_CHECK_LAUNCH("modulation");
     return 0;
 }
 
 // vec_in(y) (mmdit.py:118-126), constant over a sample
-int run_yemb(const lsl_model *m, const Workspace &ws, const float *y, int rows, hipStream_t st) {
+int run_yemb(lsl_model *m, const Workspace &ws, const float *y, int rows, hipStream_t st) {
     const lsl_weights &w = m->w;
     const int D = m->d.hidden, V = m->d.vec_in_dim;
     hipLaunchKernelGGL((k_dense_rows<false, true>), dim3((D + 3) / 4), dim3(256), 0, st, ws.hid, y, w.vec_w1, w.vec_b1,
@@ -216,13 +235,16 @@ void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream
 }
 
 // one ParallelMLPAttentionV2 sub-block on h (in place): LN+modulate -> linear1 -> attention -> linear2
-int run_block(const lsl_model *m, const Workspace &ws, int bi, float *h, const float *mods, int mod_stride, int bc, int T, int L,
+int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *mods, int mod_stride, int bc, int T, int L,
               hipStream_t st) {
     const lsl_model_desc &d = m->d;
     const lsl_block_weights &bw = m->blocks[bi];
     const int D = d.hidden, n = bc * T * L, layer = bi / 2, temporal = bi & 1;
     const float *mbase = mods + (size_t)layer * 6 * D + (temporal ? 3 * D : 0);  // shift, scale, gate
+    m->prof.begin(3, st);
     DISPATCH_D(D, launch_ln_mod_t, ws.a, h, mbase, mbase + D, mod_stride, n, T * L, st);
+    m->prof.end(3, st);
+    m->prof.begin(0, st);
 
     const float premul = (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
     if (d.head_dim_pad == 32) {
@@ -234,6 +256,7 @@ int run_block(const lsl_model *m, const Workspace &ws, int bi, float *h, const f
                          temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul};
         launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st);
     }
+    m->prof.end(0, st);
     AttnArgs aa;
     aa.qkv = ws.qkv;
     aa.z = ws.z;
@@ -245,18 +268,22 @@ int run_block(const lsl_model *m, const Workspace &ws, int bi, float *h, const f
     } else {          // sequences (b,l), positions t
         aa.S = T; aa.n_seq = bc * L; aa.inner = L; aa.outer_stride = T * L; aa.pos_stride = L;
     }
+    m->prof.begin(2, st);
     if (d.head_dim_pad == 32) launch_attention_t<32>(aa, st);
     else launch_attention_t<16>(aa, st);
+    m->prof.end(2, st);
 
+    m->prof.begin(1, st);
     EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L};
     launch_gemm((const u16 *)bw.w2, ws.z, D, n, m->K2, e2, st);
+    m->prof.end(1, st);
     LSL_CHECK_LAUNCH("block");
     return 0;
 }
 
 // One evaluation for a pass of bc trajectories; state already embedded?  No: embeds x first.
 // do_step: fuse the affine update into the head; else write the network output to `out`.
-int run_eval(const lsl_model *m, const Workspace &ws, float *x, float *out, const float *t_dev, float t_scalar, bool have_y, int bc,
+int run_eval(lsl_model *m, const Workspace &ws, float *x, float *out, const float *t_dev, float t_scalar, bool have_y, int bc,
              int T, int L, int do_step, float ax, float am, float aw, const float *noise, uint64_t seed, unsigned step,
              uint64_t elem_off, float *trace, hipStream_t st) {
     const lsl_model_desc &d = m->d;
@@ -267,21 +294,25 @@ int run_eval(const lsl_model *m, const Workspace &ws, float *x, float *out, cons
     const int mod_stride = shared ? 0 : m->MODW;
     int rc = run_mods(m, ws, t_dev, t_scalar, have_y ? ws.yemb : nullptr, rows, ws.vec, ws.mods, st);
     if (rc) return rc;
+    m->prof.begin(5, st);
     launch_embed<1>(ws.h, x, m->w.x_in_w, nullptr, nullptr, nullptr, nullptr, ws.cond_emb, n, d.in_dim, D, st);
     if (d.normalize) { DISPATCH_D(D, launch_ln_inplace_t, ws.h, n, 1e-5f, st); }
+    m->prof.end(5, st);
     LSL_CHECK_LAUNCH("embed");
     for (int bi = 0; bi < 2 * d.depth; ++bi) {
         rc = run_block(m, ws, bi, ws.h, ws.mods, mod_stride, bc, T, L, st);
         if (rc) return rc;
     }
     const float *fm = ws.mods + (size_t)d.depth * 6 * D;  // adaLN: shift, scale
+    m->prof.begin(4, st);
     DISPATCH_D(D, launch_head_t, x, out, ws.h, fm, fm + D, mod_stride, m->w.out_w, m->w.out_b, n, d.in_dim, T * L, do_step, ax, am, aw,
                noise, (unsigned long long)seed, step, (unsigned long long)elem_off, trace, st);
+    m->prof.end(4, st);
     LSL_CHECK_LAUNCH("head");
     return 0;
 }
 
-int prepare_pass(const lsl_model *m, const Workspace &ws, const float *x_cond, const int64_t *mask, const float *y, int bc, int T,
+int prepare_pass(lsl_model *m, const Workspace &ws, const float *x_cond, const int64_t *mask, const float *y, int bc, int T,
                  int L, hipStream_t st) {
     const lsl_model_desc &d = m->d;
     const int n = bc * T * L;
@@ -354,12 +385,47 @@ int lsl_model_set_weights(lsl_model *m, const lsl_weights *w) {
     return 0;
 }
 
-void lsl_model_destroy(lsl_model *m) { delete m; }
+void lsl_model_destroy(lsl_model *m) {
+    if (m) m->prof.clear();
+    delete m;
+}
+
+int lsl_profile_enable(lsl_model *m, int32_t kernel, int32_t max_launches) {
+    if (!m) return fail(-1, "null model");
+    m->prof.clear();
+    if (kernel < 0 || max_launches <= 0) return 0;
+    m->prof.ev.resize(2 * (size_t)max_launches);
+    for (auto &e : m->prof.ev)
+        if (hipEventCreate(&e) != hipSuccess) return fail(-10, "hipEventCreate failed");
+    m->prof.kernel = kernel;
+    m->prof.cap = max_launches;
+    return 0;
+}
+
+int lsl_profile_read(lsl_model *m, double *total_ms, int32_t *launches) {
+    if (!m || !total_ms || !launches) return fail(-1, "null argument");
+    double tot = 0.0;
+    for (int i = 0; i < m->prof.used; ++i) {
+        hipEventSynchronize(m->prof.ev[2 * i + 1]);
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, m->prof.ev[2 * i], m->prof.ev[2 * i + 1]) != hipSuccess) return fail(-10, "hipEventElapsedTime failed");
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = m->prof.used;
+    m->prof.used = 0;
+    return 0;
+}
 
 int lsl_model_set_chunk(lsl_model *m, int32_t c) {
     if (!m || c < 0) return fail(-1, "bad argument");
     m->chunk = c;
     return 0;
+}
+
+int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
+    if (!m || B <= 0 || T <= 0 || L <= 0) return 0;
+    return default_chunk(m, B, T, L);
 }
 
 size_t lsl_workspace_bytes(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
