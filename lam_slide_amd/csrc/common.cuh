@@ -46,6 +46,22 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// erf-GELU with erfc from Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32 rounding level):
+//   z = |x| / sqrt 2,  t = 1 / (1 + p z),  erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2)
+//   gelu(x) = x * Phi(x),  Phi(-|x|) = erfc(z) / 2  ->  x < 0: x erfc/2 ;  x >= 0: x - x erfc/2
+// No cancellation on the negative side, one v_rcp + one v_exp per element instead of libm erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float q = 0.5f * x * (p * t * e);
+    return x >= 0.0f ? x - q : q;
+}
+
 // Workgroup id remap so that consecutive logical tiles share an XCD's L2.  Hardware deals
 // workgroups round-robin over the 8 XCDs; this only affects speed, never results.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -123,6 +123,101 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_wx(GemmArgs g, Epi epi) 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Same product, operands streamed by LDS-DMA (global_load_lds_dwordx4) into an NS-deep ring of k-tiles, so
+// NS-1 k-tiles of loads stay in flight across the per-k-tile barrier (counted s_waitcnt vmcnt, raw s_barrier)
+// and no VGPRs or ds_write instructions are spent on staging.  One stage image = [BF rows of W | BT rows of X]
+// x 64 bf16; a wave instruction lands 1 KiB = 8 rows x 128 B lane-linearly, so the read-side XOR swizzle is
+// applied to the per-lane SOURCE address (both sides use the same involution chunk ^ ((row >> 1) & 7)).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BF, int BT, int NWF, int NWT, int NS, class Epi>
+__global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi) {
+    constexpr int NW = NWF * NWT;
+    constexpr int WF = BF / NWF, WT = BT / NWT;
+    constexpr int MI = WF / 32, NJ = WT / 32;
+    constexpr int STAGE = (BF + BT) * 128;  // bytes
+    constexpr int PIECES = (BF + BT) / 8;   // 1 KiB pieces per stage
+    constexpr int LPS = PIECES / NW;        // LDS-DMA instructions per wave per stage
+    static_assert(PIECES % NW == 0 && BF % 16 == 0 && BT % 16 == 0 && NS >= 2 && NS <= 4, "bad tiling");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wf = wave / NWT, wt = wave % NWT;
+    const int r = lane & 31, hf = lane >> 5;
+
+    const int ntt = (g.N + BT - 1) / BT, nft = (g.F + BF - 1) / BF;
+    const int tile = xcd_remap(blockIdx.x, ntt * nft);
+    const int f_base = (tile % nft) * BF, n_base = (tile / nft) * BT;
+
+    const u16 *src[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const int piece = wave + i * NW;
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        src[i] = row < BF ? g.W + (size_t)min(f_base + row, g.F - 1) * g.K + chunk * 8
+                          : g.X + (size_t)min(n_base + row - BF, g.N - 1) * g.K + chunk * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < LPS; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + kt * GEMM_BK),
+                                             (LDS_PTR(void))(smem + buf * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = g.K / GEMM_BK;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;  // k-tiles after this one; min(rem, NS-2) of them are already in flight
+        if (rem >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
+        else if (NS == 4 && rem == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+        const char *sb = smem + (kt % NS) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_off(wf * WF + i * 32 + r, 2 * ks + hf)));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_off(BF + wt * WT + j * 32 + r, 2 * ks + hf)));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int f0 = f_base + wf * WF + i * 32;
+        if (f0 >= g.F) continue;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n_base + wt * WT + j * 32 + r;
+            epi(acc[i][j], f0, n, hf, n < g.N);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // linear1 epilogue: + bias; q/k heads: RMS norm * scale, RoPE (q additionally * softmax scale * log2 e);
 // v: as is; mlp: exact-erf GELU.  Output bf16:  qkv[n][0 .. 3*HHD)  and  z[n][HHD .. HHD+M).
 // (mmdit.py:241-248, 129-148, 85-90, 11-18)
@@ -137,13 +232,15 @@ struct EpiLinear1 {
     int pos_div, pos_mod;  // position of token n inside its sequence: (n / pos_div) % pos_mod
     float inv_hd;          // 1 / true head_dim
     float q_premul;        // head_dim^-0.5 * log2(e), folded into q for the exp2-based softmax
+    int mode;              // 0: product path; 1: libm erff GELU; 2: ablation (skip the epilogue math; timing only)
 
     __device__ __forceinline__ void operator()(const f32x16 &acc, int f0, int n, int hf, bool valid) const {
         float v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = acc[e] + bias[f0 + acc_row(e, hf)];
         const int sec = f0 / HHD;  // 0 q, 1 k, 2 v, >= 3 mlp (wave-uniform: HHD is a multiple of 32)
-        if (sec < 2) {
+        if (mode == 2) {
+        } else if (sec < 2) {
             const float *sc = sec == 0 ? qs : ks;
             const int pos = (n / pos_div) % pos_mod;
             const float2 *tab = rope + (size_t)pos * (HDP / 2);
@@ -169,7 +266,7 @@ struct EpiLinear1 {
             }
         } else if (sec >= 3) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 16; ++e) v[e] = mode == 1 ? gelu_erf(v[e]) : gelu_fast(v[e]);
         }
         if (!valid) return;
         u16 *dst = sec < 3 ? qkv + (size_t)n * (3 * HHD) + f0 : z + (size_t)n * (HHD + M) + (f0 - 2 * HHD);

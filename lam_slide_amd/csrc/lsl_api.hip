@@ -106,9 +106,10 @@ int default_chunk(const lsl_model *m, int B, int T, int L) {
         const int v = atoi(e);
         if (v > 0) return v < B ? v : B;
     }
-    // keep one pass's activations (about 18 D + 2 M bytes per token) near the 256 MiB Infinity Cache
-    const size_t per_traj = (size_t)T * L * (18 * m->d.hidden + 2 * m->d.mlp_dim);
-    size_t c = ((size_t)192 << 20) / (per_traj ? per_traj : 1);
+    // Measured on MI355X (profiles/r01_chunk_sweep.txt): pass size barely matters between 2 and 32 trajectories
+    // of the MD17 shape (kernels are not HBM-bound), larger is marginally faster; cap a pass at about 64 Ki tokens
+    // so the workspace stays below ~1 GiB.
+    size_t c = (size_t)65536 / ((size_t)T * L ? (size_t)T * L : 1);
     if (c < 1) c = 1;
     return (int)(c < (size_t)B ? c : (size_t)B);
 }
@@ -132,7 +133,11 @@ template <int NE, int VEC>
 void launch_head_t(float *x, float *out, const float *h, const float *shift, const float *scale, int stride, const float *Wo,
                    const float *bo, int n, int C, int tpt, int do_step, float ax, float am, float aw, const float *noise,
                    unsigned long long seed, unsigned step, unsigned long long eo, float *trace, hipStream_t st) {
-    hipLaunchKernelGGL((k_head_step<NE, VEC>), dim3((n + 3) / 4), dim3(256), 0, st, x, out, h, shift, scale, stride, Wo, bo, n,
+    auto kern = k_head_step<NE, VEC>;
+    constexpr size_t lds = head_lds_bytes<NE>();
+    static bool once = (allow_lds(kern, lds), true);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3((n + HEAD_TOK - 1) / HEAD_TOK), dim3(256), lds, st, x, out, h, shift, scale, stride, Wo, bo, n,
                        C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
 }
 
@@ -159,15 +164,44 @@ int launch_embed(float *out, const float *in, const float *W, const float *b, co
     return 0;
 }
 
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <int BF, int BT, int NWF, int NWT, int NS, class Epi>
+void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
+    auto kern = k_gemm_glds<BF, BT, NWF, NWT, NS, Epi>;
+    constexpr size_t lds = (size_t)NS * (BF + BT) * 128;
+    static bool once = (allow_lds(kern, lds), true);
+    (void)once;
+    const int tiles = ((g.N + BT - 1) / BT) * ((g.F + BF - 1) / BF);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NWF * NWT * 64), lds, st, g, epi);
+}
+
+// GEMM variant (tuning knob LSL_GEMM; results are identical across variants up to fp32 summation order,
+// which is the same k order in all of them):
+//   0  128x128 tile, 4 waves, register-staged double buffer
+//   1  128x128, 4 waves, LDS-DMA ring of 2      2  128x128, 4 waves, ring of 3      3  128x128, 4 waves, ring of 4
+//   4  128(f)x256(t), 8 waves, ring of 3         5  256x256, 8 waves, ring of 2
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi, hipStream_t st) {
+    static const int variant = env_int("LSL_GEMM", 0);
+    GemmArgs g{W, X, F, N, K};
+    switch (variant) {
+        case 1: return launch_gemm_glds<128, 128, 2, 2, 2>(g, epi, st);
+        case 2: return launch_gemm_glds<128, 128, 2, 2, 3>(g, epi, st);
+        case 3: return launch_gemm_glds<128, 128, 2, 2, 4>(g, epi, st);
+        case 4: return launch_gemm_glds<128, 256, 2, 4, 3>(g, epi, st);
+        case 5: return launch_gemm_glds<256, 256, 2, 4, 2>(g, epi, st);
+        default: break;
+    }
     constexpr int BF = 128, BT = 128;
     auto kern = k_gemm_wx<BF, BT, 2, 2, Epi>;
     const size_t lds = 2 * (BF + BT) * 128;
     static bool once = (allow_lds(kern, lds), true);
     (void)once;
     const int tiles = ((N + BT - 1) / BT) * ((F + BF - 1) / BF);
-    GemmArgs g{W, X, F, N, K};
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, g, epi);
 }
 
@@ -247,13 +281,14 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     m->prof.begin(0, st);
 
     const float premul = (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
+    static const int epi_mode = env_int("LSL_EPI", 0);  // 0 product path; 1 libm erff; 2 timing-only ablation
     if (d.head_dim_pad == 32) {
         EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
-                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul};
+                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul, epi_mode};
         launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st);
     } else {
         EpiLinear1<16> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
-                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul};
+                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul, epi_mode};
         launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st);
     }
     m->prof.end(0, st);
