@@ -109,6 +109,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    net.ensure_packed(dev)
     for _ in range(args.warmup):
         one_step()
     lib = _lib.load()

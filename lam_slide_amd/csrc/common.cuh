@@ -51,15 +51,15 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 //   gelu(x) = x * Phi(x),  Phi(-|x|) = erfc(z) / 2  ->  x < 0: x erfc/2 ;  x >= 0: x - x erfc/2
 // No cancellation on the negative side, one v_rcp + one v_exp per element instead of libm erff.
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    const float q = 0.5f * x * (p * t * e);
-    return x >= 0.0f ? x - q : q;
+    // h = Phi(-|x|) = erfc(z)/2 (coefficients pre-halved);  gelu = max(x, 0) - |x| h  on both sides of 0
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    p = fmaf(t, p, 0.5f * 1.421413741f);
+    p = fmaf(t, p, 0.5f * -0.284496736f);
+    p = fmaf(t, p, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * (x * x));
+    return fmaf(-ax, p * t * e, fmaxf(x, 0.0f));
 }
 
 // Workgroup id remap so that consecutive logical tiles share an XCD's L2.  Hardware deals

@@ -27,6 +27,23 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {  // byte offset ins
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// Epilogue protocol: `epi.token(n, valid)` precomputes everything that depends only on the lane's token (row
+// pointers, position, modulation row) once per 32-token column; `epi.tile(acc, f0, tok, hf)` consumes one 32x32
+// accumulator tile whose rows are features f0 + acc_row(reg, hf) of that token.
+template <int MI, int NJ, class Epi>
+__device__ __forceinline__ void run_epilogue(const Epi &epi, f32x16 (&acc)[MI][NJ], int f_wave, int n_lane, int hf, int F, int N) {
+    typename Epi::Tok tok[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) tok[j] = epi.token(n_lane + j * 32, n_lane + j * 32 < N);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int f0 = f_wave + i * 32;
+        if (f0 >= F) continue;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) epi.tile(acc[i][j], f0, tok[j], hf);
+    }
+}
+
 template <int BF, int BT, int NWF, int NWT, class Epi>
 __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_wx(GemmArgs g, Epi epi) {
     constexpr int NT = NWF * NWT * 64;
@@ -110,16 +127,7 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_wx(GemmArgs g, Epi epi) 
         __syncthreads();
     }
 
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int f0 = f_base + wf * WF + i * 32;
-        if (f0 >= g.F) continue;  // wave-uniform
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n_base + wt * WT + j * 32 + r;
-            epi(acc[i][j], f0, n, hf, n < g.N);
-        }
-    }
+    run_epilogue<MI, NJ>(epi, acc, f_base + wf * WF, n_base + wt * WT + r, hf, g.F, g.N);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -205,21 +213,12 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi
         }
     }
 
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int f0 = f_base + wf * WF + i * 32;
-        if (f0 >= g.F) continue;  // wave-uniform
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n_base + wt * WT + j * 32 + r;
-            epi(acc[i][j], f0, n, hf, n < g.N);
-        }
-    }
+    run_epilogue<MI, NJ>(epi, acc, f_base + wf * WF, n_base + wt * WT + r, hf, g.F, g.N);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // linear1 epilogue: + bias; q/k heads: RMS norm * scale, RoPE (q additionally * softmax scale * log2 e);
-// v: as is; mlp: exact-erf GELU.  Output bf16:  qkv[n][0 .. 3*HHD)  and  z[n][HHD .. HHD+M).
+// v: as is; mlp: erf-GELU.  Output bf16:  qkv[n][0 .. 3*HHD)  and  z[n][HHD .. HHD+M).
 // (mmdit.py:241-248, 129-148, 85-90, 11-18)
 template <int HDP>
 struct EpiLinear1 {
@@ -232,48 +231,69 @@ struct EpiLinear1 {
     int pos_div, pos_mod;  // position of token n inside its sequence: (n / pos_div) % pos_mod
     float inv_hd;          // 1 / true head_dim
     float q_premul;        // head_dim^-0.5 * log2(e), folded into q for the exp2-based softmax
-    int mode;              // 0: product path; 1: libm erff GELU; 2: ablation (skip the epilogue math; timing only)
 
-    __device__ __forceinline__ void operator()(const f32x16 &acc, int f0, int n, int hf, bool valid) const {
+    struct Tok {
+        u16 *qkv_row, *z_row;  // z_row is pre-offset so that feature f lands at z_row[f]
+        const float2 *tab;
+        bool valid;
+    };
+    __device__ __forceinline__ Tok token(int n, bool valid) const {
+        Tok t;
+        const unsigned nn = valid ? (unsigned)n : 0u;
+        t.qkv_row = qkv + (size_t)nn * (3 * HHD);
+        t.z_row = z + (size_t)nn * (HHD + M) - 2 * HHD;
+        t.tab = rope + (size_t)((nn / (unsigned)pos_div) % (unsigned)pos_mod) * (HDP / 2);
+        t.valid = valid;
+        return t;
+    }
+
+    __device__ __forceinline__ void tile(const f32x16 &acc, int f0, const Tok &t, int hf) const {
         float v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = acc[e] + bias[f0 + acc_row(e, hf)];
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + f0 + 8 * q4 + 4 * hf);
+            v[4 * q4] = acc[4 * q4] + b.x;
+            v[4 * q4 + 1] = acc[4 * q4 + 1] + b.y;
+            v[4 * q4 + 2] = acc[4 * q4 + 2] + b.z;
+            v[4 * q4 + 3] = acc[4 * q4 + 3] + b.w;
+        }
         const int sec = f0 / HHD;  // 0 q, 1 k, 2 v, >= 3 mlp (wave-uniform: HHD is a multiple of 32)
-        if (mode == 2) {
-        } else if (sec < 2) {
+        if (sec < 2) {
             const float *sc = sec == 0 ? qs : ks;
-            const int pos = (n / pos_div) % pos_mod;
-            const float2 *tab = rope + (size_t)pos * (HDP / 2);
-            constexpr int GROUPS = 32 / HDP;      // heads per 32-feature tile
-            constexpr int RPG = 16 / GROUPS;      // registers per head
+            const float post = sec == 0 ? q_premul : 1.0f;
+            constexpr int GROUPS = 32 / HDP;  // heads per 32-feature tile
+            constexpr int RPG = 16 / GROUPS;  // registers per head
 #pragma unroll
             for (int gi = 0; gi < GROUPS; ++gi) {
                 float ss = 0.0f;
 #pragma unroll
-                for (int e = 0; e < RPG; ++e) ss += v[gi * RPG + e] * v[gi * RPG + e];
+                for (int e = 0; e < RPG; ++e) ss = fmaf(v[gi * RPG + e], v[gi * RPG + e], ss);
                 ss += xhalf(ss);
-                const float rr = rsqrtf(ss * inv_hd + 1e-6f);
+                const float rr = rsqrtf(fmaf(ss, inv_hd, 1e-6f)) * post;
 #pragma unroll
-                for (int e = 0; e < RPG; e += 2) {
-                    const int d = acc_row(gi * RPG + e, hf) & (HDP - 1);  // even channel inside the head
-                    const float x0 = v[gi * RPG + e] * rr * sc[d], x1 = v[gi * RPG + e + 1] * rr * sc[d + 1];
-                    const float2 cs = valid ? tab[d >> 1] : make_float2(1.0f, 0.0f);
-                    float y0 = cs.x * x0 - cs.y * x1, y1 = cs.y * x0 + cs.x * x1;
-                    if (sec == 0) { y0 *= q_premul; y1 *= q_premul; }
-                    v[gi * RPG + e] = y0;
-                    v[gi * RPG + e + 1] = y1;
+                for (int q4 = 0; q4 < RPG / 4; ++q4) {
+                    const int e = gi * RPG + 4 * q4;
+                    const int d = (8 * q4 + 4 * hf) & (HDP - 1);  // first of 4 consecutive channels inside the head
+                    const float4 s4 = *reinterpret_cast<const float4 *>(sc + d);
+                    const float4 cs = *reinterpret_cast<const float4 *>(t.tab + (d >> 1));  // (cos0, sin0, cos1, sin1)
+                    const float x0 = v[e] * rr * s4.x, x1 = v[e + 1] * rr * s4.y;
+                    const float x2 = v[e + 2] * rr * s4.z, x3 = v[e + 3] * rr * s4.w;
+                    v[e] = cs.x * x0 - cs.y * x1;
+                    v[e + 1] = cs.y * x0 + cs.x * x1;
+                    v[e + 2] = cs.z * x2 - cs.w * x3;
+                    v[e + 3] = cs.w * x2 + cs.z * x3;
                 }
             }
         } else if (sec >= 3) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = mode == 1 ? gelu_erf(v[e]) : gelu_fast(v[e]);
+            for (int e = 0; e < 16; ++e) v[e] = gelu_fast(v[e]);
         }
-        if (!valid) return;
-        u16 *dst = sec < 3 ? qkv + (size_t)n * (3 * HHD) + f0 : z + (size_t)n * (HHD + M) + (f0 - 2 * HHD);
+        if (!t.valid) return;
+        u16 *dst = (sec < 3 ? t.qkv_row : t.z_row) + f0 + 4 * hf;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             u32x2 pk = {pack2(v[4 * q4], v[4 * q4 + 1]), pack2(v[4 * q4 + 2], v[4 * q4 + 3])};
-            *reinterpret_cast<u32x2 *>(dst + 8 * q4 + 4 * hf) = pk;
+            *reinterpret_cast<u32x2 *>(dst + 8 * q4) = pk;
         }
     }
 };
@@ -285,21 +305,28 @@ struct EpiLinear2 {
     float *h;           // [N][D]
     int D, mod_stride, tokens_per_traj;
 
-    __device__ __forceinline__ void operator()(const f32x16 &acc, int f0, int n, int hf, bool valid) const {
-        if (!valid) return;
-        const float *gr = gate + (size_t)(n / tokens_per_traj) * mod_stride;
-        float *hr = h + (size_t)n * D;
+    struct Tok {
+        float *h_row;
+        const float *gate_row;
+        bool valid;
+    };
+    __device__ __forceinline__ Tok token(int n, bool valid) const {
+        const unsigned nn = valid ? (unsigned)n : 0u;
+        return Tok{h + (size_t)nn * D, gate + (size_t)(nn / (unsigned)tokens_per_traj) * mod_stride, valid};
+    }
+    __device__ __forceinline__ void tile(const f32x16 &acc, int f0, const Tok &t, int hf) const {
+        if (!t.valid) return;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             const int f = f0 + 8 * q4 + 4 * hf;
             const float4 b = *reinterpret_cast<const float4 *>(bias + f);
-            const float4 gt = *reinterpret_cast<const float4 *>(gr + f);
-            float4 hv = *reinterpret_cast<float4 *>(hr + f);
+            const float4 gt = *reinterpret_cast<const float4 *>(t.gate_row + f);
+            float4 hv = *reinterpret_cast<float4 *>(t.h_row + f);
             hv.x = fmaf(gt.x, acc[4 * q4] + b.x, hv.x);
             hv.y = fmaf(gt.y, acc[4 * q4 + 1] + b.y, hv.y);
             hv.z = fmaf(gt.z, acc[4 * q4 + 2] + b.z, hv.z);
             hv.w = fmaf(gt.w, acc[4 * q4 + 3] + b.w, hv.w);
-            *reinterpret_cast<float4 *>(hr + f) = hv;
+            *reinterpret_cast<float4 *>(t.h_row + f) = hv;
         }
     }
 };

@@ -72,59 +72,65 @@ __global__ void __launch_bounds__(256) k_dense_rows(float *out, const float *in,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Small-K projection C -> D (x_in / cond_to_emb, latent_si_v31.py:172).
+// Small-K projection C -> D (x_in / cond_to_emb, latent_si_v31.py:172), exact fp32 FMA chains over c.
 //   MODE 0 (once per sample): out = in @ W^T + bias + bias2 + mask_emb[mask]      (cond_to_emb part)
 //   MODE 1 (every evaluation): out = in @ W^T + base                              (x_in part + cached)
-template <int CMAX, int MODE>
+// Workgroup = EMB_TOK tokens.  A thread owns 4 consecutive output columns (their weight rows live in registers,
+// all output traffic is 16 bytes per lane) and walks every (256 / (D/4))-th token; the token's inputs are read
+// from LDS as wave-uniform 16-byte pieces.
+constexpr int EMB_TOK = 64;
+template <int CMAX, int MODE, int ND>  // ND output columns per thread: 4 (C <= 32), 2 (C <= 96), 1
 __global__ void __launch_bounds__(256) k_embed(float *out, const float *in, const float *W, const float *bias,
                                                const float *bias2, const float *mask_emb, const int64_t *mask,
                                                const float *base, int N, int C, int D) {
-    // A thread owns output columns d and d + blockDim.x (weight rows in registers) and walks TOK tokens whose
-    // inputs sit in LDS; the token row is read as wave-uniform (broadcast) 16-byte pieces shared by both columns.
-    constexpr int TOK = 32;
-    __shared__ __attribute__((aligned(16))) float xs[TOK][CMAX];
-    const int n0 = blockIdx.x * TOK;
-    for (int i = threadIdx.x; i < TOK * CMAX; i += blockDim.x) {
+    __shared__ __attribute__((aligned(16))) float xs[EMB_TOK][CMAX];
+    const int n0 = blockIdx.x * EMB_TOK;
+    const int ntok = min(EMB_TOK, N - n0);
+    for (int i = threadIdx.x; i < EMB_TOK * CMAX; i += 256) {
         const int tkn = i / CMAX, c = i % CMAX;
-        xs[tkn][c] = (n0 + tkn < N && c < C) ? in[(size_t)(n0 + tkn) * C + c] : 0.0f;
+        xs[tkn][c] = (tkn < ntok && c < C) ? in[(size_t)(n0 + tkn) * C + c] : 0.0f;
     }
+    const int DQ = D / ND, groups = DQ >= 256 ? 1 : 256 / DQ;
     __syncthreads();
-    for (int d0 = threadIdx.x; d0 < D; d0 += 2 * blockDim.x) {
-        const int d1 = d0 + blockDim.x;
-        const bool two = d1 < D;
-        float w0[CMAX], w1[CMAX];
+    for (int dq = threadIdx.x % (DQ < 256 ? DQ : 256); dq < DQ; dq += 256) {
+        const int tg = DQ >= 256 ? 0 : threadIdx.x / DQ, d = ND * dq;
+        if (tg >= groups) break;
+        float w[ND][CMAX];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-            w0[c] = c < C ? W[(size_t)d0 * C + c] : 0.0f;
-            w1[c] = (two && c < C) ? W[(size_t)d1 * C + c] : 0.0f;
-        }
-        float b0 = 0.0f, b1 = 0.0f;
-        if (MODE == 0) {
-            b0 = bias[d0] + bias2[d0];
-            if (two) b1 = bias[d1] + bias2[d1];
-        }
-        const int ntok = min(TOK, N - n0);
-        for (int tkn = 0; tkn < ntok; ++tkn) {
-            const int n = n0 + tkn;
-            float s0 = 0.0f, s1 = 0.0f;
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) w[j][c] = c < C ? W[(size_t)(d + j) * C + c] : 0.0f;
+        float b0[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) b0[j] = MODE == 0 ? bias[d + j] + bias2[d + j] : 0.0f;
+#pragma unroll 2
+        for (int tkn = tg; tkn < ntok; tkn += groups) {
+            const size_t row = (size_t)(n0 + tkn) * D + d;
+            float add[ND], acc[ND];
+            if (MODE == 0) {
+                const float *me = mask_emb + (mask[n0 + tkn] != 0 ? D : 0) + d;
+#pragma unroll
+                for (int j = 0; j < ND; ++j) add[j] = b0[j] + me[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < ND; ++j) add[j] = base[row + j];
+            }
+#pragma unroll
+            for (int j = 0; j < ND; ++j) acc[j] = 0.0f;
 #pragma unroll
             for (int c = 0; c < CMAX; c += 4) {
                 const float4 xv = *reinterpret_cast<const float4 *>(&xs[tkn][c]);
-                s0 = fmaf(xv.x, w0[c], s0); s1 = fmaf(xv.x, w1[c], s1);
-                s0 = fmaf(xv.y, w0[c + 1], s0); s1 = fmaf(xv.y, w1[c + 1], s1);
-                s0 = fmaf(xv.z, w0[c + 2], s0); s1 = fmaf(xv.z, w1[c + 2], s1);
-                s0 = fmaf(xv.w, w0[c + 3], s0); s1 = fmaf(xv.w, w1[c + 3], s1);
+#pragma unroll
+                for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.x, w[j][c], acc[j]);
+#pragma unroll
+                for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.y, w[j][c + 1], acc[j]);
+#pragma unroll
+                for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.z, w[j][c + 2], acc[j]);
+#pragma unroll
+                for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.w, w[j][c + 3], acc[j]);
             }
-            if (MODE == 0) {
-                const int mo = mask[n] != 0 ? D : 0;
-                s0 += b0 + mask_emb[mo + d0];
-                if (two) s1 += b1 + mask_emb[mo + d1];
-            } else {
-                s0 += base[(size_t)n * D + d0];
-                if (two) s1 += base[(size_t)n * D + d1];
-            }
-            out[(size_t)n * D + d0] = s0;
-            if (two) out[(size_t)n * D + d1] = s1;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) out[row + j] = acc[j] + add[j];
         }
     }
 }
@@ -251,7 +257,7 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 // Output head fused with the sampler update (latent_si_v31.py:185-187 + the affine step of lsl_step):
 //   m = Linear_{D->C}(LayerNorm_{1e-6}(h) * (1 + scale) + shift)          (fp32 FMA chain, exact fp32 weights)
 //   STEP: x <- ax * x + am * m + aw * w        else: out <- m
-// Workgroup = 32 tokens.  Phase 1: each wave normalises + modulates 8 token rows into LDS (fp32).
+// Persistent workgroups walk 32-token tiles.  Phase 1: each wave normalises + modulates 8 token rows into LDS (fp32).
 // Phase 2: thread (token, cg) accumulates 4 consecutive output channels over D, reading the token row and the
 // transposed weight slab W_s[cg][d] (float4 = 4 channels) from LDS; slabs of 32 channels are cycled for C > 32.
 // LDS rows are padded (+4 floats / +1 float4) so the 8 tokens / 8 channel groups of a wave hit distinct banks.
@@ -266,69 +272,80 @@ __global__ void __launch_bounds__(256) k_head_step(float *x, float *out, const f
                                                    float aw, const float *noise, unsigned long long seed, unsigned step,
                                                    unsigned long long elem_offset, float *trace) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int D = NE * 64, AS = D + 4, WS = D + 1;
+    constexpr int D = NE * 64, AS = D + 4, WS = D + 1, RPW = HEAD_TOK / 4;  // rows per wave
     float4 *Ws = reinterpret_cast<float4 *>(smem);                    // [8][WS]
     float *As = reinterpret_cast<float *>(smem + (size_t)8 * WS * 16);  // [HEAD_TOK][AS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * HEAD_TOK;
-
-    for (int tk = wave; tk < HEAD_TOK; tk += 4) {
-        const int n = n0 + tk;
-        float v[NE];
-        if (n < N) {
-            row_load<NE, VEC>(h + (size_t)n * D, lane, v);
-            float mean, rstd;
-            row_stats<NE>(v, 1e-6f, mean, rstd);
-            const size_t mo = (size_t)(n / tokens_per_traj) * mod_stride;
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const int d = row_col<NE, VEC>(lane, k);
-                v[k] = (v[k] - mean) * rstd * (1.0f + scale[mo + d]) + shift[mo + d];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NE; ++k) v[k] = 0.0f;
-        }
-#pragma unroll
-        for (int k = 0; k < NE; ++k) As[tk * AS + row_col<NE, VEC>(lane, k)] = v[k];
-    }
-
     const int tk = tid >> 3, cg = tid & 7;
-    const int n = n0 + tk;
-    for (int c0 = 0; c0 < C; c0 += 32) {
-        __syncthreads();  // As complete (first slab) / previous slab fully consumed
+    const int n_tiles = (N + HEAD_TOK - 1) / HEAD_TOK;
+    const bool w_resident = C <= 32;  // one 32-channel slab: fill it once per workgroup, then walk token tiles
+
+    auto fill_w = [&](int c0) {
+#pragma unroll 8
         for (int i = tid; i < 32 * D; i += 256) {
             const int cl = i / D, d = i - cl * D, c = c0 + cl;
             reinterpret_cast<float *>(&Ws[(cl >> 2) * WS + d])[cl & 3] = c < C ? Wo[(size_t)c * D + d] : 0.0f;
         }
-        __syncthreads();
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        const float *ar = As + tk * AS;
-        const float4 *wr = Ws + cg * WS;
-#pragma unroll 2
-        for (int d = 0; d < D; d += 4) {
-            const float4 av = *reinterpret_cast<const float4 *>(ar + d);
-            const float4 w0 = wr[d], w1 = wr[d + 1], w2 = wr[d + 2], w3 = wr[d + 3];
-            a0 = fmaf(av.x, w0.x, a0); a1 = fmaf(av.x, w0.y, a1); a2 = fmaf(av.x, w0.z, a2); a3 = fmaf(av.x, w0.w, a3);
-            a0 = fmaf(av.y, w1.x, a0); a1 = fmaf(av.y, w1.y, a1); a2 = fmaf(av.y, w1.z, a2); a3 = fmaf(av.y, w1.w, a3);
-            a0 = fmaf(av.z, w2.x, a0); a1 = fmaf(av.z, w2.y, a1); a2 = fmaf(av.z, w2.z, a2); a3 = fmaf(av.z, w2.w, a3);
-            a0 = fmaf(av.w, w3.x, a0); a1 = fmaf(av.w, w3.y, a1); a2 = fmaf(av.w, w3.z, a2); a3 = fmaf(av.w, w3.w, a3);
-        }
-        if (n < N) {
-            const float acc[4] = {a0, a1, a2, a3};
+    };
+    if (w_resident) fill_w(0);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int n0 = tile * HEAD_TOK;
+        // phase 1: all of this wave's rows are requested before any reduction, so their latencies overlap
+        float v[RPW][NE];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = c0 + 4 * cg + j;
-                if (c < C) {
-                    const float m = acc[j] + bo[c];
-                    const size_t e = (size_t)n * C + c;
-                    if (do_step) {
-                        float xn = ax * x[e] + am * m;
-                        if (aw != 0.0f) xn += aw * (noise ? noise[e] : philox_normal(seed, step, elem_offset + e));
-                        x[e] = xn;
-                        if (trace) trace[e] = xn;
-                    } else {
-                        out[e] = m;
+        for (int i = 0; i < RPW; ++i) {
+            const int n = min(n0 + wave + 4 * i, N - 1);
+            row_load<NE, VEC>(h + (size_t)n * D, lane, v[i]);
+        }
+        __syncthreads();  // previous tile's phase 2 has finished reading As (and Ws when not resident)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int n = min(n0 + wave + 4 * i, N - 1);
+            float mean, rstd;
+            row_stats<NE>(v[i], 1e-6f, mean, rstd);
+            const size_t mo = (size_t)(n / tokens_per_traj) * mod_stride;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int d = row_col<NE, VEC>(lane, k);
+                As[(wave + 4 * i) * AS + d] = (v[i][k] - mean) * rstd * (1.0f + scale[mo + d]) + shift[mo + d];
+            }
+        }
+        const int n = n0 + tk;
+        for (int c0 = 0; c0 < C; c0 += 32) {
+            if (!w_resident) {
+                if (c0) __syncthreads();  // previous slab fully consumed
+                fill_w(c0);
+            }
+            __syncthreads();  // As (and Ws) visible
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            const float *ar = As + tk * AS;
+            const float4 *wr = Ws + cg * WS;
+#pragma unroll 2
+            for (int d = 0; d < D; d += 4) {
+                const float4 av = *reinterpret_cast<const float4 *>(ar + d);
+                const float4 w0 = wr[d], w1 = wr[d + 1], w2 = wr[d + 2], w3 = wr[d + 3];
+                a0 = fmaf(av.x, w0.x, a0); a1 = fmaf(av.x, w0.y, a1); a2 = fmaf(av.x, w0.z, a2); a3 = fmaf(av.x, w0.w, a3);
+                a0 = fmaf(av.y, w1.x, a0); a1 = fmaf(av.y, w1.y, a1); a2 = fmaf(av.y, w1.z, a2); a3 = fmaf(av.y, w1.w, a3);
+                a0 = fmaf(av.z, w2.x, a0); a1 = fmaf(av.z, w2.y, a1); a2 = fmaf(av.z, w2.z, a2); a3 = fmaf(av.z, w2.w, a3);
+                a0 = fmaf(av.w, w3.x, a0); a1 = fmaf(av.w, w3.y, a1); a2 = fmaf(av.w, w3.z, a2); a3 = fmaf(av.w, w3.w, a3);
+            }
+            if (n < N) {
+                const float acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + 4 * cg + j;
+                    if (c < C) {
+                        const float m = acc[j] + bo[c];
+                        const size_t e = (size_t)n * C + c;
+                        if (do_step) {
+                            float xn = ax * x[e] + am * m;
+                            if (aw != 0.0f) xn += aw * (noise ? noise[e] : philox_normal(seed, step, elem_offset + e));
+                            x[e] = xn;
+                            if (trace) trace[e] = xn;
+                        } else {
+                            out[e] = m;
+                        }
                     }
                 }
             }

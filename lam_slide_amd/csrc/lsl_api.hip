@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -137,7 +138,7 @@ void launch_head_t(float *x, float *out, const float *h, const float *shift, con
     constexpr size_t lds = head_lds_bytes<NE>();
     static bool once = (allow_lds(kern, lds), true);
     (void)once;
-    hipLaunchKernelGGL(kern, dim3((n + HEAD_TOK - 1) / HEAD_TOK), dim3(256), lds, st, x, out, h, shift, scale, stride, Wo, bo, n,
+    hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, 256)), dim3(256), lds, st, x, out, h, shift, scale, stride, Wo, bo, n,
                        C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
 }
 
@@ -156,11 +157,11 @@ void launch_head_t(float *x, float *out, const float *h, const float *shift, con
 template <int MODE>
 int launch_embed(float *out, const float *in, const float *W, const float *b, const float *b2, const float *me,
                  const int64_t *mask, const float *base, int n, int C, int D, hipStream_t st) {
-    const dim3 grid((n + 31) / 32), blk(D < 256 ? D : 256);
-    if (C <= 32) hipLaunchKernelGGL((k_embed<32, MODE>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
-    else if (C <= 64) hipLaunchKernelGGL((k_embed<64, MODE>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
-    else if (C <= 96) hipLaunchKernelGGL((k_embed<96, MODE>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
-    else hipLaunchKernelGGL((k_embed<128, MODE>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
+    const dim3 grid((n + EMB_TOK - 1) / EMB_TOK), blk(256);
+    if (C <= 32) hipLaunchKernelGGL((k_embed<32, MODE, 4>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
+    else if (C <= 64) hipLaunchKernelGGL((k_embed<64, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
+    else if (C <= 96) hipLaunchKernelGGL((k_embed<96, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
+    else hipLaunchKernelGGL((k_embed<128, MODE, 1>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
     return 0;
 }
 
@@ -281,14 +282,13 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     m->prof.begin(0, st);
 
     const float premul = (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
-    static const int epi_mode = env_int("LSL_EPI", 0);  // 0 product path; 1 libm erff; 2 timing-only ablation
     if (d.head_dim_pad == 32) {
         EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
-                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul, epi_mode};
+                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul};
         launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st);
     } else {
         EpiLinear1<16> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
-                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul, epi_mode};
+                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul};
         launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st);
     }
     m->prof.end(0, st);

@@ -11,10 +11,3 @@ import json,sys
 d=json.loads(sys.stdin.read()); b=d['breakdown']
 print('traj/s %.2f  path TF %.1f  lin1 TF %.1f | ms: '%(d['value'], d['roofline']['whole_path_tflops'], d['roofline']['achieved']) + ' '.join('%s %.1f'%(k,v['ms']) for k,v in b.items()))"
 done
-echo "== epilogue ablation on variant ${2:-0}"
-for e in 1 2; do
-  LSL_GEMM=${2:-0} LSL_EPI=$e python bench.py --steps 1 --warmup 1 --batch 32 --no-cpu --breakdown 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); b=d['breakdown']
-print('LSL_EPI=$e traj/s %.2f lin1 TF %.1f | ms: '%(d['value'], d['roofline']['achieved']) + ' '.join('%s %.1f'%(k,v['ms']) for k,v in b.items()))"
-done
