@@ -139,15 +139,25 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_wx(GemmArgs g, Epi epi) 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BF, int BT, int NWF, int NWT, int NS, class Epi>
+// byte offset of 16-byte chunk `chunk` of row `row` inside a [rows][BK] bf16 stage image (BK = 64 or 32)
+template <int BK>
+__device__ __forceinline__ int swz_bk(int row, int chunk) {
+    if (BK == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+template <int BF, int BT, int NWF, int NWT, int BK, int NS, class Epi>
 __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi) {
     constexpr int NW = NWF * NWT;
     constexpr int WF = BF / NWF, WT = BT / NWT;
     constexpr int MI = WF / 32, NJ = WT / 32;
-    constexpr int STAGE = (BF + BT) * 128;  // bytes
-    constexpr int PIECES = (BF + BT) / 8;   // 1 KiB pieces per stage
-    constexpr int LPS = PIECES / NW;        // LDS-DMA instructions per wave per stage
-    static_assert(PIECES % NW == 0 && BF % 16 == 0 && BT % 16 == 0 && NS >= 2 && NS <= 4, "bad tiling");
+    constexpr int ROWB = BK * 2;                 // bytes per stage row
+    constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (8 or 4)
+    constexpr int RPP = 1024 / ROWB;             // rows per 1 KiB LDS-DMA piece (8 or 16)
+    constexpr int STAGE = (BF + BT) * ROWB;      // bytes
+    constexpr int PIECES = (BF + BT) / RPP;      // 1 KiB pieces per stage
+    constexpr int LPS = PIECES / NW;             // LDS-DMA instructions per wave per stage
+    static_assert(PIECES % NW == 0 && BF % 16 == 0 && BT % 16 == 0 && NS >= 2 && NS <= 6 && (BK == 32 || BK == 64), "bad tiling");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -163,15 +173,15 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi
 #pragma unroll
     for (int i = 0; i < LPS; ++i) {
         const int piece = wave + i * NW;
-        const int row = piece * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = piece * RPP + lane / CPR;
+        const int chunk = (swz_bk<BK>(row, lane % CPR) - row * ROWB) >> 4;  // logical chunk stored at this physical slot
         src[i] = row < BF ? g.W + (size_t)min(f_base + row, g.F - 1) * g.K + chunk * 8
                           : g.X + (size_t)min(n_base + row - BF, g.N - 1) * g.K + chunk * 8;
     }
     auto issue = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < LPS; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + kt * GEMM_BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + kt * BK),
                                              (LDS_PTR(void))(smem + buf * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
     };
 
@@ -183,29 +193,34 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int nk = g.K / GEMM_BK;
+    const int nk = g.K / BK;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s);
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int rem = nk - 1 - kt;  // k-tiles after this one; min(rem, NS-2) of them are already in flight
-        if (rem >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
-        else if (NS == 4 && rem == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
+        // k-tiles after this one that are already in flight: min(nk - 1 - kt, NS - 2); wait for everything older
+        const int ahead = min(nk - 1 - kt, NS - 2);
+        switch (ahead) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<LPS>(); break;
+            case 2: wait_vmcnt<2 * LPS>(); break;
+            case 3: wait_vmcnt<3 * LPS>(); break;
+            default: wait_vmcnt<4 * LPS>(); break;
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
         const char *sb = smem + (kt % NS) * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 af[MI], bfr[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                af[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_off(wf * WF + i * 32 + r, 2 * ks + hf)));
+                af[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_bk<BK>(wf * WF + i * 32 + r, 2 * ks + hf)));
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_off(BF + wt * WT + j * 32 + r, 2 * ks + hf)));
+                bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_bk<BK>(BF + wt * WT + j * 32 + r, 2 * ks + hf)));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll

@@ -170,31 +170,35 @@ int env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-template <int BF, int BT, int NWF, int NWT, int NS, class Epi>
+template <int BF, int BT, int NWF, int NWT, int BK, int NS, class Epi>
 void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
-    auto kern = k_gemm_glds<BF, BT, NWF, NWT, NS, Epi>;
-    constexpr size_t lds = (size_t)NS * (BF + BT) * 128;
+    auto kern = k_gemm_glds<BF, BT, NWF, NWT, BK, NS, Epi>;
+    constexpr size_t lds = (size_t)NS * (BF + BT) * BK * 2;
     static bool once = (allow_lds(kern, lds), true);
     (void)once;
     const int tiles = ((g.N + BT - 1) / BT) * ((g.F + BF - 1) / BF);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NWF * NWT * 64), lds, st, g, epi);
 }
 
-// GEMM variant (tuning knob LSL_GEMM; results are identical across variants up to fp32 summation order,
-// which is the same k order in all of them):
-//   0  128x128 tile, 4 waves, register-staged double buffer
-//   1  128x128, 4 waves, LDS-DMA ring of 2      2  128x128, 4 waves, ring of 3      3  128x128, 4 waves, ring of 4
-//   4  128(f)x256(t), 8 waves, ring of 3         5  256x256, 8 waves, ring of 2
+// GEMM variant (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
+//   0  128x128 tile, 4 waves, BK 64, register-staged double buffer
+//   LDS-DMA ring variants  (features x tokens, waves, BK, stages):
+//   1  128x128 4w 64x2    5  256x256 8w 64x2    6  256x256 8w 32x4    7  256x256 8w 32x3    8  128x256 4w 32x3
+//   9  128x256 8w 32x4   10  128x128 4w 32x4   11  256x128 4w 32x3   12  256x256 8w 32x5
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi, hipStream_t st) {
-    static const int variant = env_int("LSL_GEMM", 0);
+    static const int variant = env_int("LSL_GEMM", 5);
     GemmArgs g{W, X, F, N, K};
     switch (variant) {
-        case 1: return launch_gemm_glds<128, 128, 2, 2, 2>(g, epi, st);
-        case 2: return launch_gemm_glds<128, 128, 2, 2, 3>(g, epi, st);
-        case 3: return launch_gemm_glds<128, 128, 2, 2, 4>(g, epi, st);
-        case 4: return launch_gemm_glds<128, 256, 2, 4, 3>(g, epi, st);
-        case 5: return launch_gemm_glds<256, 256, 2, 4, 2>(g, epi, st);
+        case 1: return launch_gemm_glds<128, 128, 2, 2, 64, 2>(g, epi, st);
+        case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2>(g, epi, st);
+        case 6: return launch_gemm_glds<256, 256, 2, 4, 32, 4>(g, epi, st);
+        case 7: return launch_gemm_glds<256, 256, 2, 4, 32, 3>(g, epi, st);
+        case 8: return launch_gemm_glds<128, 256, 2, 2, 32, 3>(g, epi, st);
+        case 9: return launch_gemm_glds<128, 256, 2, 4, 32, 4>(g, epi, st);
+        case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 4>(g, epi, st);
+        case 11: return launch_gemm_glds<256, 128, 2, 2, 32, 3>(g, epi, st);
+        case 12: return launch_gemm_glds<256, 256, 2, 4, 32, 5>(g, epi, st);
         default: break;
     }
     constexpr int BF = 128, BT = 128;
