@@ -212,19 +212,36 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi
         asm volatile("" ::: "memory");
         if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
         const char *sb = smem + (kt % NS) * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 af[MI], bfr[NJ];
+        // Fragments are double-buffered across the 16-deep k sub-steps: the ds_read_b128 of sub-step ks+1 are
+        // issued before the MFMAs of sub-step ks (hipcc otherwise emits read / lgkmcnt(0) / 2 MFMAs chains that
+        // expose the LDS latency every two MFMAs); only the first sub-step of a k-tile waits on LDS.
+        auto load_frags = [&](int ks, bf16x8(&a)[MI], bf16x8(&b)[NJ]) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                af[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_bk<BK>(wf * WF + i * 32 + r, 2 * ks + hf)));
+                a[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_bk<BK>(wf * WF + i * 32 + r, 2 * ks + hf)));
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_bk<BK>(BF + wt * WT + j * 32 + r, 2 * ks + hf)));
+                b[j] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_bk<BK>(BF + wt * WT + j * 32 + r, 2 * ks + hf)));
+        };
+        auto mfma_all = [&](const bf16x8(&a)[MI], const bf16x8(&b)[NJ]) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        };
+        constexpr int KS = BK / 16;
+        bf16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
+        load_frags(0, a0, b0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            load_frags(ks + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_all(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < KS) load_frags(ks + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_all(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

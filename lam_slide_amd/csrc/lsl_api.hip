@@ -183,22 +183,15 @@ void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 // GEMM variant (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
 //   0  128x128 tile, 4 waves, BK 64, register-staged double buffer
 //   LDS-DMA ring variants  (features x tokens, waves, BK, stages):
-//   1  128x128 4w 64x2    5  256x256 8w 64x2    6  256x256 8w 32x4    7  256x256 8w 32x3    8  128x256 4w 32x3
-//   9  128x256 8w 32x4   10  128x128 4w 32x4   11  256x128 4w 32x3   12  256x256 8w 32x5
+//   5  256x256 8w 64x2    7  256x256 8w 32x3    10  128x128 4w 32x4
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi, hipStream_t st) {
     static const int variant = env_int("LSL_GEMM", 5);
     GemmArgs g{W, X, F, N, K};
     switch (variant) {
-        case 1: return launch_gemm_glds<128, 128, 2, 2, 64, 2>(g, epi, st);
         case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2>(g, epi, st);
-        case 6: return launch_gemm_glds<256, 256, 2, 4, 32, 4>(g, epi, st);
         case 7: return launch_gemm_glds<256, 256, 2, 4, 32, 3>(g, epi, st);
-        case 8: return launch_gemm_glds<128, 256, 2, 2, 32, 3>(g, epi, st);
-        case 9: return launch_gemm_glds<128, 256, 2, 4, 32, 4>(g, epi, st);
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 4>(g, epi, st);
-        case 11: return launch_gemm_glds<256, 128, 2, 2, 32, 3>(g, epi, st);
-        case 12: return launch_gemm_glds<256, 256, 2, 4, 32, 5>(g, epi, st);
         default: break;
     }
     constexpr int BF = 128, BT = 128;
