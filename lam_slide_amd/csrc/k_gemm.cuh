@@ -5,137 +5,28 @@
 // (W = nn.Linear weight [out,in], X = activations [tokens, in]; both are k-contiguous, so both MFMA
 // operands are plain 16-byte row reads).  With features on the accumulator rows and tokens on the
 // lanes, one lane holds 16 of the 32 features of a tile for ONE token: per-head RMS norm and the RoPE
-// pair rotation are in-register (+ one exchange with lane^32), and every store is 4 consecutive
-// features of one token.
+// pair rotation are in-register (+ one exchange with lane^32).
 //
-// Tiling: workgroup tile BF x BT (features x tokens), BK = 64, NWF x NWT waves, each wave owns
-// (BF/NWF) x (BT/NWT) as 32x32 MFMA tiles.  LDS double buffer, register-staged global loads
-// (issue early / write late), XOR-swizzled 16-byte chunks so ds_read_b128 fragment reads are
-// conflict-free:  physical chunk = chunk ^ ((row >> 1) & 7)  for 128-byte rows.
+// Operand feed: LDS-DMA (global_load_lds_dwordx4) into an NS-deep ring of k-tiles; NS-1 k-tiles of loads
+// stay in flight across the per-k-tile barrier (counted s_waitcnt vmcnt, raw s_barrier), no VGPRs or
+// ds_write instructions are spent on staging.  One stage image = [BF rows of W | BT rows of X] x BK bf16; a
+// wave instruction lands 1 KiB lane-linearly, so the read-side XOR swizzle of the 16-byte chunks (which makes
+// the ds_read_b128 fragment reads conflict-free) is applied to the per-lane SOURCE address.
+//
+// Output: measured on MI355X (profiles/r01_*), per-lane stores straight from the accumulator layout touch 32
+// cache lines per wave instruction (16-32 B each) and made the kernels store-transaction-bound, not MFMA- or
+// load-bound.  The epilogue therefore transposes each wave's sub-tile through wave-private LDS (reusing the
+// operand ring) and writes whole 128/256-byte row segments, 16 B per lane.
 #pragma once
 #include "common.cuh"
-
-constexpr int GEMM_BK = 64;
 
 struct GemmArgs {
     const u16 *W;  // [F][K] bf16
     const u16 *X;  // [N][K] bf16
     int F, N, K;
+    int probe;  // TIMING PROBES ONLY (results wrong): bit0 skip operand loads, bit1 skip LDS reads + MFMAs, bit2 skip epilogue
 };
 
-__device__ __forceinline__ int swz_off(int row, int chunk) {  // byte offset inside a [rows][64] bf16 tile
-    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-// Epilogue protocol: `epi.token(n, valid)` precomputes everything that depends only on the lane's token (row
-// pointers, position, modulation row) once per 32-token column; `epi.tile(acc, f0, tok, hf)` consumes one 32x32
-// accumulator tile whose rows are features f0 + acc_row(reg, hf) of that token.
-template <int MI, int NJ, class Epi>
-__device__ __forceinline__ void run_epilogue(const Epi &epi, f32x16 (&acc)[MI][NJ], int f_wave, int n_lane, int hf, int F, int N) {
-    typename Epi::Tok tok[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) tok[j] = epi.token(n_lane + j * 32, n_lane + j * 32 < N);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int f0 = f_wave + i * 32;
-        if (f0 >= F) continue;  // wave-uniform
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) epi.tile(acc[i][j], f0, tok[j], hf);
-    }
-}
-
-template <int BF, int BT, int NWF, int NWT, class Epi>
-__global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_wx(GemmArgs g, Epi epi) {
-    constexpr int NT = NWF * NWT * 64;
-    constexpr int WF = BF / NWF, WT = BT / NWT;  // wave tile
-    constexpr int MI = WF / 32, NJ = WT / 32;    // MFMA tiles per wave
-    constexpr int W_LOADS = BF * 8 / NT, X_LOADS = BT * 8 / NT;  // 16-byte chunks per thread per k-tile
-    static_assert(BF * 8 % NT == 0 && BT * 8 % NT == 0, "tile/threads mismatch");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Ws = smem;                           // [2][BF][64] bf16
-    char *Xs = smem + 2 * BF * 128;            // [2][BT][64] bf16
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wf = wave / NWT, wt = wave % NWT;
-    const int r = lane & 31, hf = lane >> 5;
-
-    const int ntt = (g.N + BT - 1) / BT, nft = (g.F + BF - 1) / BF;
-    const int tile = xcd_remap(blockIdx.x, ntt * nft);
-    const int f_base = (tile % nft) * BF, n_base = (tile / nft) * BT;
-
-    // global -> register staging: thread covers row (tid/8 + i*NT/8), chunk tid%8
-    const int lrow = tid >> 3, lchunk = tid & 7;
-    u32x4 wreg[W_LOADS], xreg[X_LOADS];
-    const u16 *wsrc[W_LOADS];
-    const u16 *xsrc[X_LOADS];
-#pragma unroll
-    for (int i = 0; i < W_LOADS; ++i) {
-        const int f = min(f_base + lrow + i * (NT / 8), g.F - 1);
-        wsrc[i] = g.W + (size_t)f * g.K + lchunk * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < X_LOADS; ++i) {
-        const int n = min(n_base + lrow + i * (NT / 8), g.N - 1);
-        xsrc[i] = g.X + (size_t)n * g.K + lchunk * 8;
-    }
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < W_LOADS; ++i) wreg[i] = *reinterpret_cast<const u32x4 *>(wsrc[i] + kt * GEMM_BK);
-#pragma unroll
-        for (int i = 0; i < X_LOADS; ++i) xreg[i] = *reinterpret_cast<const u32x4 *>(xsrc[i] + kt * GEMM_BK);
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < W_LOADS; ++i)
-            *reinterpret_cast<u32x4 *>(Ws + buf * BF * 128 + swz_off(lrow + i * (NT / 8), lchunk)) = wreg[i];
-#pragma unroll
-        for (int i = 0; i < X_LOADS; ++i)
-            *reinterpret_cast<u32x4 *>(Xs + buf * BT * 128 + swz_off(lrow + i * (NT / 8), lchunk)) = xreg[i];
-    };
-
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int nk = g.K / GEMM_BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const char *wb = Ws + buf * BF * 128, *xb = Xs + buf * BT * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[MI], bfr[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                af[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(wb + swz_off(wf * WF + i * 32 + r, 2 * ks + hf)));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xb + swz_off(wt * WT + j * 32 + r, 2 * ks + hf)));
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
-        }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-
-    run_epilogue<MI, NJ>(epi, acc, f_base + wf * WF, n_base + wt * WT + r, hf, g.F, g.N);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Same product, operands streamed by LDS-DMA (global_load_lds_dwordx4) into an NS-deep ring of k-tiles, so
-// NS-1 k-tiles of loads stay in flight across the per-k-tile barrier (counted s_waitcnt vmcnt, raw s_barrier)
-// and no VGPRs or ds_write instructions are spent on staging.  One stage image = [BF rows of W | BT rows of X]
-// x 64 bf16; a wave instruction lands 1 KiB = 8 rows x 128 B lane-linearly, so the read-side XOR swizzle is
-// applied to the per-lane SOURCE address (both sides use the same involution chunk ^ ((row >> 1) & 7)).
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -146,17 +37,35 @@ __device__ __forceinline__ int swz_bk(int row, int chunk) {
     return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
 }
 
-template <int BF, int BT, int NWF, int NWT, int BK, int NS, class Epi>
+// wave-private output staging: rows of CH 16-byte chunks, chunk index XOR-swizzled by the row so that both the
+// column-wise accumulator writes and the row-wise 16-byte reads spread over the banks
+template <int CH>
+__device__ __forceinline__ int stage_off(int row, int chunk) { return (row * CH + (chunk ^ (row & (CH - 1)))) << 4; }
+
+template <int BF, int BT, int NWF, int NWT, int BK, int NS, bool PERSIST, class Epi>
+struct GemmCfg {
+    static constexpr int NW = NWF * NWT;
+    static constexpr int WF = BF / NWF, WT = BT / NWT;
+    static constexpr size_t ring_bytes = (size_t)NS * (BF + BT) * BK * 2;
+    static constexpr size_t stage_bytes = (size_t)NW * Epi::template wave_stage_bytes<WF, WT>();
+    // PERSIST: the output staging sits BEHIND the ring, so the next tile's first k-tiles stream into the ring
+    // while the epilogue of the current tile drains through the staging area; otherwise staging overlays the ring
+    static constexpr size_t stage_base = PERSIST ? ring_bytes : 0;
+    static constexpr size_t lds_bytes = PERSIST ? ring_bytes + stage_bytes : (ring_bytes > stage_bytes ? ring_bytes : stage_bytes);
+    static_assert(lds_bytes <= 163840, "LDS budget (160 KiB per workgroup)");
+};
+
+template <int BF, int BT, int NWF, int NWT, int BK, int NS, bool PERSIST, class Epi>
 __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi) {
-    constexpr int NW = NWF * NWT;
-    constexpr int WF = BF / NWF, WT = BT / NWT;
+    using Cfg = GemmCfg<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>;
+    constexpr int NW = Cfg::NW, WF = Cfg::WF, WT = Cfg::WT;
     constexpr int MI = WF / 32, NJ = WT / 32;
-    constexpr int ROWB = BK * 2;                 // bytes per stage row
-    constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (8 or 4)
-    constexpr int RPP = 1024 / ROWB;             // rows per 1 KiB LDS-DMA piece (8 or 16)
-    constexpr int STAGE = (BF + BT) * ROWB;      // bytes
-    constexpr int PIECES = (BF + BT) / RPP;      // 1 KiB pieces per stage
-    constexpr int LPS = PIECES / NW;             // LDS-DMA instructions per wave per stage
+    constexpr int ROWB = BK * 2;             // bytes per stage row
+    constexpr int CPR = ROWB / 16;           // 16-byte chunks per row (8 or 4)
+    constexpr int RPP = 1024 / ROWB;         // rows per 1 KiB LDS-DMA piece (8 or 16)
+    constexpr int STAGE = (BF + BT) * ROWB;  // bytes
+    constexpr int PIECES = (BF + BT) / RPP;  // 1 KiB pieces per stage
+    constexpr int LPS = PIECES / NW;         // LDS-DMA instructions per wave per stage
     static_assert(PIECES % NW == 0 && BF % 16 == 0 && BT % 16 == 0 && NS >= 2 && NS <= 6 && (BK == 32 || BK == 64), "bad tiling");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -165,26 +74,58 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi
     const int wf = wave / NWT, wt = wave % NWT;
     const int r = lane & 31, hf = lane >> 5;
 
-    const int ntt = (g.N + BT - 1) / BT, nft = (g.F + BF - 1) / BF;
-    const int tile = xcd_remap(blockIdx.x, ntt * nft);
-    const int f_base = (tile % nft) * BF, n_base = (tile / nft) * BT;
-
-    const u16 *src[LPS];
-#pragma unroll
-    for (int i = 0; i < LPS; ++i) {
-        const int piece = wave + i * NW;
-        const int row = piece * RPP + lane / CPR;
-        const int chunk = (swz_bk<BK>(row, lane % CPR) - row * ROWB) >> 4;  // logical chunk stored at this physical slot
-        src[i] = row < BF ? g.W + (size_t)min(f_base + row, g.F - 1) * g.K + chunk * 8
-                          : g.X + (size_t)min(n_base + row - BF, g.N - 1) * g.K + chunk * 8;
-    }
-    auto issue = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < LPS; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + kt * BK),
-                                             (LDS_PTR(void))(smem + buf * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
+    // Persistent workgroups: virtual block v = blockIdx.x + s * gridDim.x walks the tile list; xcd_remap keeps the
+    // feature tiles that share one token tile on one XCD and close in time (gridDim.x is a multiple of 8).
+    const int ntt = (g.N + BT - 1) / BT, nft = (g.F + BF - 1) / BF, ntiles = ntt * nft;
+    const int nk = g.K / BK;
+    int f_base = 0, n_base = 0;
+    // LDS-DMA sources: piece p = wave + i * NW covers stage rows p*RPP .. p*RPP+RPP-1; pieces below BF/RPP are W rows,
+    // the rest X rows.  Both operand buffers are padded to whole tiles by the host (packing.py / carve()), so there is
+    // no clamping and each operand needs one per-lane base pointer plus a uniform step between pieces.
+    constexpr int WP = BF / RPP / NW, XP = BT / RPP / NW;  // pieces per wave per stage from W and from X
+    static_assert(BF % (RPP * NW) == 0 && BT % (RPP * NW) == 0 && WP + XP == LPS, "stage split");
+    const int lrow = wave * RPP + lane / CPR;
+    const int lchunk = (swz_bk<BK>(lrow, lane % CPR) - lrow * ROWB) >> 4;  // logical chunk stored at this lane's slot
+    const size_t piece_step = (size_t)NW * RPP * g.K;                       // elements between a wave's pieces
+    const u16 *srcW = nullptr, *srcX = nullptr;
+    auto set_tile = [&](int v) {
+        const int tile = xcd_remap(v, ntiles);
+        f_base = (tile % nft) * BF;
+        n_base = (tile / nft) * BT;
+        srcW = g.W + (size_t)(f_base + lrow) * g.K + lchunk * 8;
+        srcX = g.X + (size_t)(n_base + lrow) * g.K + lchunk * 8;
     };
+    auto issue = [&](int kt, int buf) {
+        if (g.probe & 1) return;
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcW + i * piece_step + kt * BK),
+                                             (LDS_PTR(void))(smem + buf * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < XP; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcX + i * piece_step + kt * BK),
+                                             (LDS_PTR(void))(smem + buf * STAGE + (wave + (WP + i) * NW) * 1024), 16, 0, 0);
+    };
+    // fragment read offsets: the swizzle term depends only on (lane, k sub-step) because every tile starts on a
+    // multiple of 16 rows; per-tile row offsets are compile-time immediates
+    constexpr int KSUB = BK / 16;
+    int offA[KSUB], offB[KSUB];
+#pragma unroll
+    for (int ks = 0; ks < KSUB; ++ks) {
+        offA[ks] = swz_bk<BK>(r, 2 * ks + hf) + wf * WF * ROWB;
+        offB[ks] = swz_bk<BK>(r, 2 * ks + hf) + (BF + wt * WT) * ROWB;
+    }
+    auto prologue = [&]() {
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nk) issue(s, s);
+    };
+    char *stage = smem + Cfg::stage_base + (size_t)wave * Epi::template wave_stage_bytes<WF, WT>();
 
+    set_tile(blockIdx.x);
+    prologue();
+    for (int v = blockIdx.x; v < ntiles; v += PERSIST ? gridDim.x : ntiles) {
+    const bool first_tile = v == (int)blockIdx.x;
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -193,14 +134,11 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int nk = g.K / BK;
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue(s, s);
-
     for (int kt = 0; kt < nk; ++kt) {
-        // k-tiles after this one that are already in flight: min(nk - 1 - kt, NS - 2); wait for everything older
-        const int ahead = min(nk - 1 - kt, NS - 2);
+        // k-tiles after this one that are already in flight: min(nk - 1 - kt, NS - 2); wait for everything older.
+        // On later tiles the previous epilogue's stores are younger than this tile's first k-tiles in the vmcnt
+        // queue, so the first wait drains everything (the k-tiles were issued a whole epilogue ago).
+        const int ahead = (kt == 0 && !first_tile) ? 0 : min(nk - 1 - kt, NS - 2);
         switch (ahead) {
             case 0: wait_vmcnt<0>(); break;
             case 1: wait_vmcnt<LPS>(); break;
@@ -213,15 +151,12 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi
         if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
         const char *sb = smem + (kt % NS) * STAGE;
         // Fragments are double-buffered across the 16-deep k sub-steps: the ds_read_b128 of sub-step ks+1 are
-        // issued before the MFMAs of sub-step ks (hipcc otherwise emits read / lgkmcnt(0) / 2 MFMAs chains that
-        // expose the LDS latency every two MFMAs); only the first sub-step of a k-tile waits on LDS.
+        // issued before the MFMAs of sub-step ks (hipcc otherwise emits read / lgkmcnt(0) / 2 MFMAs chains).
         auto load_frags = [&](int ks, bf16x8(&a)[MI], bf16x8(&b)[NJ]) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                a[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_bk<BK>(wf * WF + i * 32 + r, 2 * ks + hf)));
+            for (int i = 0; i < MI; ++i) a[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + offA[ks] + i * 32 * ROWB));
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                b[j] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + swz_bk<BK>(BF + wt * WT + j * 32 + r, 2 * ks + hf)));
+            for (int j = 0; j < NJ; ++j) b[j] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + offB[ks] + j * 32 * ROWB));
         };
         auto mfma_all = [&](const bf16x8(&a)[MI], const bf16x8(&b)[NJ]) {
 #pragma unroll
@@ -230,22 +165,33 @@ __global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi
                 for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
         };
         constexpr int KS = BK / 16;
-        bf16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
-        load_frags(0, a0, b0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks += 2) {
-            load_frags(ks + 1, a1, b1);
+        if (g.probe & 2) continue;
+        if (BK == 32) {
+            bf16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
+            load_frags(0, a0, b0);
+            load_frags(1, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
             mfma_all(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + 2 < KS) load_frags(ks + 2, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
             mfma_all(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
+        } else {  // BK = 64: one fragment set (the 256-VGPR budget of an 8-wave workgroup has no room for two)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 a0[MI], b0[NJ];
+                load_frags(ks, a0, b0);
+                mfma_all(a0, b0);
+            }
         }
     }
 
-    run_epilogue<MI, NJ>(epi, acc, f_base + wf * WF, n_base + wt * WT + r, hf, g.F, g.N);
+    __syncthreads();  // every wave is done with the operand ring
+    const int fw = f_base + wf * WF, nw = n_base + wt * WT;
+    if (PERSIST && v + (int)gridDim.x < ntiles) {  // stream the next tile's first k-tiles while this tile's epilogue runs
+        set_tile(v + gridDim.x);
+        prologue();
+    }
+    if (!(g.probe & 4)) epi.template run<MI, NJ>(acc, stage, fw, nw, lane, g.F, g.N);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -264,23 +210,10 @@ struct EpiLinear1 {
     float inv_hd;          // 1 / true head_dim
     float q_premul;        // head_dim^-0.5 * log2(e), folded into q for the exp2-based softmax
 
-    struct Tok {
-        u16 *qkv_row, *z_row;  // z_row is pre-offset so that feature f lands at z_row[f]
-        const float2 *tab;
-        bool valid;
-    };
-    __device__ __forceinline__ Tok token(int n, bool valid) const {
-        Tok t;
-        const unsigned nn = valid ? (unsigned)n : 0u;
-        t.qkv_row = qkv + (size_t)nn * (3 * HHD);
-        t.z_row = z + (size_t)nn * (HHD + M) - 2 * HHD;
-        t.tab = rope + (size_t)((nn / (unsigned)pos_div) % (unsigned)pos_mod) * (HDP / 2);
-        t.valid = valid;
-        return t;
-    }
+    template <int WF, int WT>
+    static constexpr size_t wave_stage_bytes() { return (size_t)(WF < 64 ? WF : 64) * WT * 2; }  // 64-feature slab
 
-    __device__ __forceinline__ void tile(const f32x16 &acc, int f0, const Tok &t, int hf) const {
-        float v[16];
+    __device__ __forceinline__ void values(const f32x16 &acc, int f0, const float2 *tab, int hf, float (&v)[16]) const {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             const float4 b = *reinterpret_cast<const float4 *>(bias + f0 + 8 * q4 + 4 * hf);
@@ -304,10 +237,11 @@ struct EpiLinear1 {
                 const float rr = rsqrtf(fmaf(ss, inv_hd, 1e-6f)) * post;
 #pragma unroll
                 for (int q4 = 0; q4 < RPG / 4; ++q4) {
+                    __builtin_amdgcn_sched_barrier(0);  // do not hoist the next group's table loads (VGPR budget)
                     const int e = gi * RPG + 4 * q4;
                     const int d = (8 * q4 + 4 * hf) & (HDP - 1);  // first of 4 consecutive channels inside the head
                     const float4 s4 = *reinterpret_cast<const float4 *>(sc + d);
-                    const float4 cs = *reinterpret_cast<const float4 *>(t.tab + (d >> 1));  // (cos0, sin0, cos1, sin1)
+                    const float4 cs = *reinterpret_cast<const float4 *>(tab + (d >> 1));  // (cos0, sin0, cos1, sin1)
                     const float x0 = v[e] * rr * s4.x, x1 = v[e + 1] * rr * s4.y;
                     const float x2 = v[e + 2] * rr * s4.z, x3 = v[e + 3] * rr * s4.w;
                     v[e] = cs.x * x0 - cs.y * x1;
@@ -318,14 +252,57 @@ struct EpiLinear1 {
             }
         } else if (sec >= 3) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = gelu_fast(v[e]);
+            for (int e = 0; e < 16; ++e) {
+                if ((e & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                v[e] = gelu_fast(v[e]);
+            }
         }
-        if (!t.valid) return;
-        u16 *dst = (sec < 3 ? t.qkv_row : t.z_row) + f0 + 4 * hf;
+    }
+
+    template <int MI, int NJ>
+    __device__ __forceinline__ void run(f32x16 (&acc)[MI][NJ], char *stage, int f_wave, int n_wave, int lane, int F, int N) const {
+        constexpr int WT = NJ * 32, GI = MI < 2 ? MI : 2, CH = GI * 4;  // slab of GI*32 features: CH 16-byte chunks per row
+        constexpr int RPI = 64 / CH;                                     // token rows written per store instruction
+        const int r = lane & 31, hf = lane >> 5;
+        const float2 *tab[NJ];
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            u32x2 pk = {pack2(v[4 * q4], v[4 * q4 + 1]), pack2(v[4 * q4 + 2], v[4 * q4 + 3])};
-            *reinterpret_cast<u32x2 *>(dst + 8 * q4) = pk;
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned n = (unsigned)min(n_wave + j * 32 + r, N - 1);
+            tab[j] = rope + (size_t)((n / (unsigned)pos_div) % (unsigned)pos_mod) * (HDP / 2);
+        }
+        const int chunk = lane % CH;
+#pragma unroll
+        for (int i0 = 0; i0 < MI; i0 += GI) {
+            if (f_wave + i0 * 32 >= F) continue;  // wave-uniform
+#pragma unroll
+            for (int ii = 0; ii < GI; ++ii) {
+                const int f0 = f_wave + (i0 + ii) * 32;
+                if (f0 >= F) continue;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    __builtin_amdgcn_sched_barrier(0);  // keep one tile's temporaries live at a time (VGPR budget)
+                    float v[16];
+                    values(acc[i0 + ii][j], f0, tab[j], hf, v);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        u32x2 pk = {pack2(v[4 * q4], v[4 * q4 + 1]), pack2(v[4 * q4 + 2], v[4 * q4 + 3])};
+                        *reinterpret_cast<u32x2 *>(stage + stage_off<CH>(j * 32 + r, 4 * ii + q4) + 8 * hf) = pk;
+                    }
+                }
+            }
+            // row-wise flush: CH lanes cover the slab of one token (16 B each), RPI tokens per instruction
+            const int f = f_wave + i0 * 32 + 8 * chunk;
+            const bool f_ok = f < F;
+            const bool to_qkv = f < 3 * HHD;
+#pragma unroll 4
+            for (int row0 = 0; row0 < WT; row0 += RPI) {
+                const int row = row0 + lane / CH, n = n_wave + row;
+                const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + stage_off<CH>(row, chunk));
+                if (f_ok && n < N) {
+                    u16 *dst = to_qkv ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
+                    *reinterpret_cast<u32x4 *>(dst) = val;
+                }
+            }
         }
     }
 };
@@ -337,28 +314,44 @@ struct EpiLinear2 {
     float *h;           // [N][D]
     int D, mod_stride, tokens_per_traj;
 
-    struct Tok {
-        float *h_row;
-        const float *gate_row;
-        bool valid;
-    };
-    __device__ __forceinline__ Tok token(int n, bool valid) const {
-        const unsigned nn = valid ? (unsigned)n : 0u;
-        return Tok{h + (size_t)nn * D, gate + (size_t)(nn / (unsigned)tokens_per_traj) * mod_stride, valid};
-    }
-    __device__ __forceinline__ void tile(const f32x16 &acc, int f0, const Tok &t, int hf) const {
-        if (!t.valid) return;
+    template <int WF, int WT>
+    static constexpr size_t wave_stage_bytes() { return (size_t)32 * WT * 4; }  // one 32-feature slab of the wave tile
+
+    template <int MI, int NJ>
+    __device__ __forceinline__ void run(f32x16 (&acc)[MI][NJ], char *stage, int f_wave, int n_wave, int lane, int F, int N) const {
+        constexpr int WT = NJ * 32, CH = 8;  // 32 fp32 features = 8 chunks of 16 B per staged token row
+        const int r = lane & 31, hf = lane >> 5;
+        const int chunk = lane & 7;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const int f = f0 + 8 * q4 + 4 * hf;
+        for (int i = 0; i < MI; ++i) {
+            const int f0 = f_wave + i * 32;
+            if (f0 >= F) continue;  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 v = make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
+                    *reinterpret_cast<float4 *>(stage + stage_off<CH>(j * 32 + r, 2 * q4 + hf)) = v;
+                }
+            __builtin_amdgcn_sched_barrier(0);  // one slab's temporaries live at a time (VGPR budget)
+            // 8 lanes cover the 128-byte slab of one token row; 8 token rows per instruction
+            const int f = f0 + 4 * chunk;
             const float4 b = *reinterpret_cast<const float4 *>(bias + f);
-            const float4 gt = *reinterpret_cast<const float4 *>(t.gate_row + f);
-            float4 hv = *reinterpret_cast<float4 *>(t.h_row + f);
-            hv.x = fmaf(gt.x, acc[4 * q4] + b.x, hv.x);
-            hv.y = fmaf(gt.y, acc[4 * q4 + 1] + b.y, hv.y);
-            hv.z = fmaf(gt.z, acc[4 * q4 + 2] + b.z, hv.z);
-            hv.w = fmaf(gt.w, acc[4 * q4 + 3] + b.w, hv.w);
-            *reinterpret_cast<float4 *>(t.h_row + f) = hv;
+#pragma unroll 2
+            for (int row0 = 0; row0 < WT; row0 += 8) {
+                const int row = row0 + (lane >> 3), n = n_wave + row;
+                const float4 a = *reinterpret_cast<const float4 *>(stage + stage_off<CH>(row, chunk));
+                if (n < N) {
+                    const float4 gt = *reinterpret_cast<const float4 *>(gate + (size_t)((unsigned)n / (unsigned)tokens_per_traj) * mod_stride + f);
+                    float *hp = h + (size_t)n * D + f;
+                    float4 hv = *reinterpret_cast<float4 *>(hp);
+                    hv.x = fmaf(gt.x, a.x + b.x, hv.x);
+                    hv.y = fmaf(gt.y, a.y + b.y, hv.y);
+                    hv.z = fmaf(gt.z, a.z + b.z, hv.z);
+                    hv.w = fmaf(gt.w, a.w + b.w, hv.w);
+                    *reinterpret_cast<float4 *>(hp) = hv;
+                }
+            }
         }
     }
 };

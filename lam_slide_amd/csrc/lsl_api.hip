@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -94,9 +95,10 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.hid = (float *)take((size_t)bc * D * 4);
     ws.vec = (float *)take((size_t)bc * D * 4);
     ws.mods = (float *)take((size_t)bc * m->MODW * 4);
-    ws.a = (u16 *)take(n * D * 2);
+    const size_t n_pad = align_up(n, 256);  // GEMM operand rows: whole 256-token tiles are read without clamping
+    ws.a = (u16 *)take(n_pad * D * 2);
     ws.qkv = (u16 *)take(n * 3 * m->HHD * 2);
-    ws.z = (u16 *)take(n * m->K2 * 2);
+    ws.z = (u16 *)take(n_pad * m->K2 * 2);
     ws.bytes = off;
     return ws;
 }
@@ -170,37 +172,52 @@ int env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-template <int BF, int BT, int NWF, int NWT, int BK, int NS, class Epi>
+int device_cus() {
+    static const int n = [] {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+        return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }();
+    return n;
+}
+
+template <int BF, int BT, int NWF, int NWT, int BK, int NS, bool PERSIST, class Epi>
 void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
-    auto kern = k_gemm_glds<BF, BT, NWF, NWT, BK, NS, Epi>;
-    constexpr size_t lds = (size_t)NS * (BF + BT) * BK * 2;
+    auto kern = k_gemm_glds<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>;
+    constexpr size_t lds = GemmCfg<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>::lds_bytes;
     static bool once = (allow_lds(kern, lds), true);
     (void)once;
     const int tiles = ((g.N + BT - 1) / BT) * ((g.F + BF - 1) / BF);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NWF * NWT * 64), lds, st, g, epi);
+    int grid = tiles;
+    if (PERSIST) {  // as many workgroups as fit at once (LDS-limited), a multiple of 8 so the XCD mapping stays regular
+        const int per_cu = (int)(163840 / lds) < 1 ? 1 : (int)(163840 / lds);
+        grid = device_cus() * per_cu;
+        grid -= grid % 8;
+        if (grid > tiles) grid = tiles;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWF * NWT * 64), lds, st, g, epi);
 }
 
-// GEMM variant (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
-//   0  128x128 tile, 4 waves, BK 64, register-staged double buffer
-//   LDS-DMA ring variants  (features x tokens, waves, BK, stages):
-//   5  256x256 8w 64x2    7  256x256 8w 32x3    10  128x128 4w 32x4
+// GEMM tiling (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
+//   (features x tokens, waves, BK x ring stages):
+//   5  256x256 8w 64x2, one tile per workgroup          6  256x256 8w 32x3, persistent workgroups + next-tile prefetch
+//   7  256x256 8w 32x3, one tile per workgroup          8  256x256 8w 32x2            10  128x128 4w 32x3
+// Default (-1): 6 for linear1 (K = D is short, the heavy epilogue overlaps the next tile's loads) and 5 for linear2,
+// the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt).
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi, hipStream_t st) {
-    static const int variant = env_int("LSL_GEMM", 5);
-    GemmArgs g{W, X, F, N, K};
+    static const int forced = env_int("LSL_GEMM", -1);
+    const int variant = forced >= 0 ? forced : (std::is_same<Epi, EpiLinear2>::value ? 5 : 6);
+    static const int probe = env_int("LSL_PROBE", 0);
+    GemmArgs g{W, X, F, N, K, probe};
     switch (variant) {
-        case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2>(g, epi, st);
-        case 7: return launch_gemm_glds<256, 256, 2, 4, 32, 3>(g, epi, st);
-        case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 4>(g, epi, st);
-        default: break;
+        case 6: return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, epi, st);
+        case 7: return launch_gemm_glds<256, 256, 2, 4, 32, 3, false>(g, epi, st);
+        case 8: return launch_gemm_glds<256, 256, 2, 4, 32, 2, false>(g, epi, st);
+        case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
+        default: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
     }
-    constexpr int BF = 128, BT = 128;
-    auto kern = k_gemm_wx<BF, BT, 2, 2, Epi>;
-    const size_t lds = 2 * (BF + BT) * 128;
-    static bool once = (allow_lds(kern, lds), true);
-    (void)once;
-    const int tiles = ((N + BT - 1) / BT) * ((F + BF - 1) / BF);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, g, epi);
 }
 
 template <int HDP>

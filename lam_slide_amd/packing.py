@@ -82,8 +82,9 @@ def pack_block(sd, pre: str, dm: PackedDims, device) -> Dict[str, torch.Tensor]:
     w2 = sd[pre + ".linear2.weight"].detach().float().cpu()
     b2 = sd[pre + ".linear2.bias"].detach().float().cpu()
     assert w1.shape == (3 * D + M, D) and w2.shape == (D, D + M), (w1.shape, w2.shape)
-    w1p = torch.zeros(dm.f1, D)
-    b1p = torch.zeros(dm.f1)
+    # rows are padded with zeros to whole 256-row GEMM tiles: the LDS-DMA loader reads full tiles without clamping
+    w1p = torch.zeros(_round_up(dm.f1, 256), D)
+    b1p = torch.zeros(_round_up(dm.f1, 256))
     for sec in range(3):
         src_w = w1[sec * D:(sec + 1) * D].reshape(H, hd, D)
         src_b = b1[sec * D:(sec + 1) * D].reshape(H, hd)
@@ -93,9 +94,9 @@ def pack_block(sd, pre: str, dm: PackedDims, device) -> Dict[str, torch.Tensor]:
         dst_b[:, :hd] = src_b
     w1p[3 * dm.hhd:3 * dm.hhd + M] = w1[3 * D:]
     b1p[3 * dm.hhd:3 * dm.hhd + M] = b1[3 * D:]
-    w2p = torch.zeros(D, dm.k2)
-    w2p[:, :dm.hhd].view(D, H, hdp)[:, :, :hd] = w2[:, :D].reshape(D, H, hd)
-    w2p[:, dm.hhd:dm.hhd + M] = w2[:, D:]
+    w2p = torch.zeros(_round_up(D, 256), dm.k2)
+    w2p[:D, :dm.hhd].view(D, H, hdp)[:, :, :hd] = w2[:, :D].reshape(D, H, hd)
+    w2p[:D, dm.hhd:dm.hhd + M] = w2[:, D:]
     qs = torch.zeros(hdp)
     ks = torch.zeros(hdp)
     qs[:hd] = sd[pre + ".norm.query_norm.scale"].detach().float().cpu()

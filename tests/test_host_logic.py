@@ -73,13 +73,14 @@ def test_packing_preserves_the_linear_maps(hidden, heads, mlp):
     dm = make_dims(1, 8, hidden, heads, mlp, None, False, 10000)
     pk = pack_block(p, "blocks.0.spatial_block", dm, "cpu")
     H, hd, hdp, D, M = heads, hidden // heads, dm.head_dim_pad, hidden, sh.mlp_dim
-    assert pk["w1"].shape == (dm.f1, D) and pk["w2"].shape == (D, dm.k2) and dm.k2 % 64 == 0 and dm.hhd % 32 == 0
+    assert pk["w1"].shape == (-(-dm.f1 // 256) * 256, D) and pk["w2"].shape == (-(-D // 256) * 256, dm.k2) and dm.k2 % 64 == 0 and dm.hhd % 32 == 0
+    assert float(pk["w1"][dm.f1:].float().abs().sum()) == 0 and float(pk["w2"][D:].float().abs().sum()) == 0
     w1 = pk["w1"].float()
     rows = torch.cat([w1[s * dm.hhd:(s + 1) * dm.hhd].view(H, hdp, D)[:, :hd].reshape(H * hd, D) for s in range(3)] + [w1[3 * dm.hhd:3 * dm.hhd + M]])
     assert torch.equal(rows, p["blocks.0.spatial_block.linear1.weight"].to(torch.bfloat16).float())
     pad = w1[: dm.hhd].view(H, hdp, D)[:, hd:]
     assert float(pad.abs().sum()) == 0
-    w2 = pk["w2"].float()
+    w2 = pk["w2"].float()[:D]
     cols = torch.cat([w2[:, : dm.hhd].view(D, H, hdp)[:, :, :hd].reshape(D, H * hd), w2[:, dm.hhd:dm.hhd + M]], dim=1)
     assert torch.equal(cols, p["blocks.0.spatial_block.linear2.weight"].to(torch.bfloat16).float())
     assert torch.equal(pk["qs"][:hd], p["blocks.0.spatial_block.norm.query_norm.scale"]) and float(pk["qs"][hd:].abs().sum()) == 0
