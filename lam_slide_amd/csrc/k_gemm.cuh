@@ -56,7 +56,7 @@ struct GemmCfg {
 };
 
 template <int BF, int BT, int NWF, int NWT, int BK, int NS, bool PERSIST, class Epi>
-__global__ void __launch_bounds__(NWF *NWT * 64) k_gemm_glds(GemmArgs g, Epi epi) {
+__global__ void __launch_bounds__(NWF *NWT * 64, 2) k_gemm_glds(GemmArgs g, Epi epi) {  // >= 2 waves/SIMD: at most 256 VGPRs
     using Cfg = GemmCfg<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>;
     constexpr int NW = Cfg::NW, WF = Cfg::WF, WT = Cfg::WT;
     constexpr int MI = WF / 32, NJ = WT / 32;

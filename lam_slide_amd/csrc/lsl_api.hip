@@ -216,6 +216,8 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
         case 7: return launch_gemm_glds<256, 256, 2, 4, 32, 3, false>(g, epi, st);
         case 8: return launch_gemm_glds<256, 256, 2, 4, 32, 2, false>(g, epi, st);
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
+        case 11: return launch_gemm_glds<256, 128, 2, 2, 32, 2, false>(g, epi, st);
+        case 12: return launch_gemm_glds<128, 256, 2, 2, 32, 2, false>(g, epi, st);
         default: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
     }
 }
