@@ -145,3 +145,113 @@ __global__ void __launch_bounds__(NW * 64) k_attention(AttnArgs a) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Short sequences (S <= 32 * NKT <= 256: every axis of the MD17 / pedestrian / NBA configs, both axes of peptide's
+// spatial attention): softmax is the plain two-pass form (one max pass, one exp/sum/PV pass, no running rescale of
+// O) -- per score element: max, sub, exp2, add, half a cvt; the scores are recomputed in the second pass.  Measured on
+// MI355X the online form above spent 17 VALU instructions per score element (profiles/r01_rocprof_summary.txt:
+// VALU : MFMA = 68 : 1), which is what bounds attention at head_dim 32, not the MFMAs.
+template <int HDP, int NW, int ITEMS, int NKT>
+__global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = HDP * 2, CPR = ROWB / 16, KS = HDP / 16, WPI = NW / ITEMS, Sp = NKT * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int S = a.S;
+    const int item_local = wave / WPI, wsub = wave % WPI;
+    const long item = (long)blockIdx.x * ITEMS + item_local;
+    const bool item_ok = item < (long)a.n_seq * a.H;
+    const int seq = item_ok ? (int)(item / a.H) : 0, head = item_ok ? (int)(item % a.H) : 0;
+    const size_t tok0 = (size_t)(seq / a.inner) * a.outer_stride + (seq % a.inner);
+    const size_t rs = (size_t)3 * a.HHD;
+    char *Ks = smem + (size_t)item_local * 2 * Sp * ROWB;
+    char *Vs = Ks + (size_t)Sp * ROWB;
+    {
+        const int ltid = wsub * 64 + lane, lthreads = WPI * 64;
+        const u16 *kbase = a.qkv + tok0 * rs + a.HHD + head * HDP;
+        const u16 *vbase = kbase + a.HHD;
+        for (int i = ltid; i < Sp * CPR; i += lthreads) {
+            const int row = i / CPR, ch = i % CPR;
+            u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (row < S && item_ok) {
+                const size_t off = (size_t)row * a.pos_stride * rs + ch * 8;
+                kv = *reinterpret_cast<const u32x4 *>(kbase + off);
+                vv = *reinterpret_cast<const u32x4 *>(vbase + off);
+            }
+            *reinterpret_cast<u32x4 *>(Ks + k_swz<HDP>(row, ch)) = kv;
+            *reinterpret_cast<u32x4 *>(Vs + row * ROWB + ch * 16) = vv;
+        }
+    }
+    __syncthreads();
+
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, grp = lane >> 4;
+    const int v_off = (4 * (grp >> 1) + gq) * ROWB + ((HDP == 32 ? (grp & 1) * 16 : 0) + 4 * gp) * 2;
+    f32x16 zero;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero[e] = 0.0f;
+    const int nqt = (S + 31) >> 5;
+
+    for (int qt = wsub; qt < nqt; qt += WPI) {
+        const int qpos = min(qt * 32 + r, S - 1);
+        const u16 *qrow = a.qkv + (tok0 + (size_t)qpos * a.pos_stride) * rs + head * HDP;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qrow + 16 * s + 8 * hf));
+
+        // pass 1: row maximum only (scores are recomputed in pass 2: two extra MFMAs per tile are far cheaper than
+        // keeping 16 * NKT score registers live, which costs the occupancy that hides the LDS / exp latencies)
+        auto scores = [&](int kt) {
+            f32x16 t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(kt * 32 + r, hf))), qf[0], zero);
+            if (KS == 2)
+                t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(kt * 32 + r, 2 + hf))), qf[KS - 1], t);
+            if (kt * 32 + 32 > S) {  // wave-uniform: zero-padded keys of the last tile do not take part
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kt * 32 + acc_row(e, hf) >= S) t[e] = -INFINITY;
+            }
+            return t;
+        };
+        float mx = -INFINITY;
+#pragma unroll 2
+        for (int kt = 0; kt < NKT; ++kt) {
+            const f32x16 t = scores(kt);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[e]);
+        }
+        mx = fmaxf(mx, xhalf(mx));
+        float sum = 0.0f;
+        f32x16 o = zero;
+#pragma unroll 2
+        for (int kt = 0; kt < NKT; ++kt) {
+            const f32x16 t = scores(kt);
+            float p[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                p[e] = __builtin_amdgcn_exp2f(t[e] - mx);
+                sum += p[e];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4 pw = {pack2(p[8 * s], p[8 * s + 1]), pack2(p[8 * s + 2], p[8 * s + 3]),
+                            pack2(p[8 * s + 4], p[8 * s + 5]), pack2(p[8 * s + 6], p[8 * s + 7])};
+                const char *vb = Vs + (kt * 32 + 16 * s) * ROWB + v_off;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb + 8 * ROWB));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o = mfma32(__builtin_bit_cast(bf16x8, vv), as_bf16x8(pw), o);
+            }
+        }
+        const float inv_l = 1.0f / (sum + xhalf(sum));
+        const int qglob = qt * 32 + r;
+        if (qglob < S && item_ok) {
+            u16 *dst = a.z + (tok0 + (size_t)qglob * a.pos_stride) * a.zw + head * HDP;
+#pragma unroll
+            for (int q4 = 0; q4 < HDP / 8; ++q4) {
+                u32x2 pk = {pack2(o[4 * q4] * inv_l, o[4 * q4 + 1] * inv_l), pack2(o[4 * q4 + 2] * inv_l, o[4 * q4 + 3] * inv_l)};
+                *reinterpret_cast<u32x2 *>(dst + 8 * q4 + 4 * hf) = pk;
+            }
+        }
+    }
+}

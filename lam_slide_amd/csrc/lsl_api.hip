@@ -222,9 +222,27 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     }
 }
 
+template <int HDP, int NW, int ITEMS, int NKT>
+void launch_attention_rows(const AttnArgs &a, hipStream_t st) {
+    auto kern = k_attention_rows<HDP, NW, ITEMS, NKT>;
+    constexpr size_t lds = (size_t)ITEMS * 2 * NKT * 32 * HDP * 2;
+    static bool once = (allow_lds(kern, lds), true);
+    (void)once;
+    const long items = (long)a.n_seq * a.H;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((items + ITEMS - 1) / ITEMS)), dim3(NW * 64), lds, st, a);
+}
+
 template <int HDP>
 void launch_attention_t(const AttnArgs &a, hipStream_t st) {
     const int Sp = (a.S + 31) & ~31;
+    static const int online = env_int("LSL_ATTN_ONLINE", 0);  // 1: force the online-softmax kernel (A/B measurements)
+    if (Sp <= 256 && !online) {  // whole score row in registers
+        if (Sp <= 32) return launch_attention_rows<HDP, 4, 4, 1>(a, st);
+        if (Sp <= 64) return launch_attention_rows<HDP, 4, 2, 2>(a, st);
+        if (Sp <= 128) return launch_attention_rows<HDP, 4, 1, 4>(a, st);
+        if (Sp <= 192) return launch_attention_rows<HDP, 4, 1, 6>(a, st);
+        return launch_attention_rows<HDP, 4, 1, 8>(a, st);
+    }
     const long items = (long)a.n_seq * a.H;
     const size_t per_item = (size_t)2 * Sp * HDP * 2;
     if (Sp <= 32) {

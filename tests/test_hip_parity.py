@@ -262,3 +262,51 @@ def test_error_behaviour_matches_reference(dev):
         s.sample_sde(diffusion_form="bogus")
     with pytest.raises(NotImplementedError):
         s.sample_sde(last_step="bogus")
+
+
+# ---- the other BASELINE.json configurations (reduced batch; weights from oracle.random_params) -------------------------
+CONFIG_SHAPES = {
+    # name: (NetShape kwargs, B, T, L, cond frames, sampler, kwargs)
+    "pedestrian": (dict(depth=6, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2, vec_in_dim=256, normalize=True), 40, 20, 2, 8, "ODE",
+                   {"sampling_method": "euler", "num_steps": 11}),
+    "nba": (dict(depth=6, in_dim=32, hidden_size=256, num_heads=16, mlp_ratio=4, vec_in_dim=256, normalize=True), 24, 20, 8, 5, "ODE",
+            {"sampling_method": "euler", "num_steps": 11}),
+    "peptide_T300": (dict(depth=7, in_dim=96, hidden_size=384, num_heads=16, mlp_ratio=4), 2, 300, 2, 1, "SDE", {"num_steps": 6}),
+    "peptide_T1000": (dict(depth=7, in_dim=96, hidden_size=384, num_heads=16, mlp_ratio=4), 1, 1000, 2, 1, "ODE",
+                      {"sampling_method": "euler", "num_steps": 3}),
+    "md17_ref": (dict(depth=4, in_dim=32, hidden_size=256, num_heads=16, mlp_ratio=2), 2, 30, 192, 10, "ODE",
+                 {"sampling_method": "euler", "num_steps": 4}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONFIG_SHAPES))
+def test_baseline_config_shapes(name, dev):
+    """Every model family of BASELINE.json (head_dim 16 / 24 / 32, S from 2 to 1000, C = 32 / 96, class conditioning,
+    normalize) through the fused sampler against the oracle, final latents within 3e-3 relative L2."""
+    from lam_slide_amd import CreateTransport, Sampler
+    from oracle import harness, latent_net, transport as otr
+    kw, B, T, L, cond, method, skw = CONFIG_SHAPES[name]
+    sh = latent_net.NetShape(**kw)
+    p = latent_net.random_params(sh, seed=11)
+    net = build_net(sh, p, dev)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(B, T, L, sh.in_dim, generator=g)
+    init = torch.randn(B, T, L, sh.in_dim, generator=g)
+    y = torch.randn(B, sh.vec_in_dim, generator=g) if sh.vec_in_dim else None
+    xc, mask = harness.setup_conditioning(lat, (0, cond), True)
+    mk = {"x_cond": xc.to(dev), "x_cond_mask": mask.to(dev)}
+    if y is not None:
+        mk["y"] = y.to(dev)
+    s = Sampler(CreateTransport("GVP", "data")(), fused=True)
+    if method == "SDE":
+        n = skw["num_steps"]
+        noise = torch.randn(n - 1, B, T, L, sh.in_dim, generator=g)
+        got = s.sample_sde(**{"diffusion_form": "linear", "last_step": "Mean", **skw}, noise=noise.to(dev))(init.to(dev), net.forward, **mk)[-1]
+        want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, mask, y, "SDE", skw, noise=list(noise), single_eval=True)
+    else:
+        got = s.get_sample_fn("ODE", skw)(init.to(dev), net.forward, **mk)[-1]
+        want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, mask, y, "ODE", skw)
+    assert s.last_path == "fused"
+    err = rel_l2(got.cpu(), want)
+    print(f"{name}: final latents rel L2 {err:.3e}")
+    assert err < 3e-3, (name, err)
