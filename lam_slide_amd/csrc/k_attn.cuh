@@ -155,10 +155,11 @@ __global__ void __launch_bounds__(NW * 64) k_attention(AttnArgs a) {
 template <int HDP, int NW, int ITEMS, int NKT>
 __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ROWB = HDP * 2, CPR = ROWB / 16, KS = HDP / 16, WPI = NW / ITEMS, Sp = NKT * 32;
+    constexpr int ROWB = HDP * 2, CPR = ROWB / 16, KS = HDP / 16, WPI = NW / ITEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
     const int S = a.S;
+    const int nkt = NKT > 0 ? NKT : (S + 31) >> 5, Sp = nkt * 32;  // NKT = 0: key-tile count known at run time only
     const int item_local = wave / WPI, wsub = wave % WPI;
     const long item = (long)blockIdx.x * ITEMS + item_local;
     const bool item_ok = item < (long)a.n_seq * a.H;
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
         };
         float mx = -INFINITY;
 #pragma unroll 2
-        for (int kt = 0; kt < NKT; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             const f32x16 t = scores(kt);
 #pragma unroll
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[e]);
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
         float sum = 0.0f;
         f32x16 o = zero;
 #pragma unroll 2
-        for (int kt = 0; kt < NKT; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             const f32x16 t = scores(kt);
             float p[16];
 #pragma unroll
@@ -253,5 +254,90 @@ __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
                 *reinterpret_cast<u32x2 *>(dst + 8 * q4 + 4 * hf) = pk;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tiny sequences (S <= 8: spatial attention of the pedestrian (L = 2), NBA (L = 8) and peptide (L = 2) models).
+// A 32 x 32 MFMA tile would be >= 94 % padding; here one lane owns one (query token, head): S dot products of
+// head_dim, softmax over <= 8 scores in registers, S axpys.  K/V rows of a sequence are shared by its S lanes
+// and come from L1/L2; lanes are ordered (token, head) so a wave reads whole token rows.
+template <int HDP>
+__global__ void __launch_bounds__(256) k_attention_tiny(AttnArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int S = a.S;
+    if (idx >= (long)a.n_seq * S * a.H) return;
+    const int head = (int)(idx % a.H);
+    const long qi = idx / a.H;
+    const int seq = (int)(qi / S), pos = (int)(qi % S);
+    const size_t tok0 = (size_t)(seq / a.inner) * a.outer_stride + (seq % a.inner);
+    const size_t rs = (size_t)3 * a.HHD;
+    const u16 *base = a.qkv + tok0 * rs + head * HDP;
+    float q[HDP];
+    {
+        const u16 *qrow = base + (size_t)pos * a.pos_stride * rs;
+#pragma unroll
+        for (int c = 0; c < HDP / 8; ++c) {
+            const u32x4 w = *reinterpret_cast<const u32x4 *>(qrow + 8 * c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q[8 * c + 2 * k] = __uint_as_float(w[k] << 16);
+                q[8 * c + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+            }
+        }
+    }
+    float sc[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = -INFINITY;
+        if (j < S) {
+            const u16 *krow = base + a.HHD + (size_t)j * a.pos_stride * rs;
+            float d = 0.0f;
+#pragma unroll
+            for (int c = 0; c < HDP / 8; ++c) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(krow + 8 * c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    d = fmaf(q[8 * c + 2 * k], __uint_as_float(w[k] << 16), d);
+                    d = fmaf(q[8 * c + 2 * k + 1], __uint_as_float(w[k] & 0xffff0000u), d);
+                }
+            }
+            sc[j] = d;
+            mx = fmaxf(mx, d);
+        }
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = j < S ? __builtin_amdgcn_exp2f(sc[j] - mx) : 0.0f;
+        sum += sc[j];
+    }
+    // the reference rounds the probabilities to the value dtype only implicitly (fp32 SDPA); keep p in fp32 here
+    float o[HDP];
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) o[d] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < S) {
+            const u16 *vrow = base + 2 * a.HHD + (size_t)j * a.pos_stride * rs;
+#pragma unroll
+            for (int c = 0; c < HDP / 8; ++c) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(vrow + 8 * c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[8 * c + 2 * k] = fmaf(sc[j], __uint_as_float(w[k] << 16), o[8 * c + 2 * k]);
+                    o[8 * c + 2 * k + 1] = fmaf(sc[j], __uint_as_float(w[k] & 0xffff0000u), o[8 * c + 2 * k + 1]);
+                }
+            }
+        }
+    }
+    const float inv = 1.0f / sum;
+    u16 *dst = a.z + (tok0 + (size_t)pos * a.pos_stride) * a.zw + head * HDP;
+#pragma unroll
+    for (int c = 0; c < HDP / 8; ++c) {
+        u32x4 w = {pack2(o[8 * c] * inv, o[8 * c + 1] * inv), pack2(o[8 * c + 2] * inv, o[8 * c + 3] * inv),
+                   pack2(o[8 * c + 4] * inv, o[8 * c + 5] * inv), pack2(o[8 * c + 6] * inv, o[8 * c + 7] * inv)};
+        *reinterpret_cast<u32x4 *>(dst + 8 * c) = w;
     }
 }

@@ -72,6 +72,60 @@ __global__ void __launch_bounds__(256) k_dense_rows(float *out, const float *in,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Same contract as k_dense_rows for MANY rows (class-conditioned batches: one conditioning row per trajectory, up to
+// thousands): a 64 x 64 (rows x outputs) register-tiled fp32 product, K in chunks of 16 through LDS (stored
+// k-major so the float4 reads of 4 rows / 4 outputs are conflict-free).  The wave-per-output kernel above walks the
+// rows serially and took 40 of 60 ms per sampling call of the pedestrian model at 1280 rows.
+template <bool PRE_SILU, bool POST_SILU>
+__global__ void __launch_bounds__(256) k_dense_tiled(float *out, const float *in, const float *W, const float *bias,
+                                                     const float *add, int rows, int I, int O, int add_stride) {
+    __shared__ __attribute__((aligned(16))) float As[16][64 + 4];
+    __shared__ __attribute__((aligned(16))) float Ws[16][64 + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int r0 = blockIdx.y * 64, o0 = blockIdx.x * 64;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    const int lr = tid >> 2, lk = (tid & 3) * 4;  // loader: row (or output) lr, k offset lk..lk+3
+    for (int k0 = 0; k0 < I; k0 += 16) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + lr < rows && k0 + lk < I) a = *reinterpret_cast<const float4 *>(in + (size_t)(r0 + lr) * I + k0 + lk);
+        if (o0 + lr < O && k0 + lk < I) w = *reinterpret_cast<const float4 *>(W + (size_t)(o0 + lr) * I + k0 + lk);
+        if (PRE_SILU) a = make_float4(silu(a.x), silu(a.y), silu(a.z), silu(a.w));
+        __syncthreads();
+        As[lk][lr] = a.x; As[lk + 1][lr] = a.y; As[lk + 2][lr] = a.z; As[lk + 3][lr] = a.w;
+        Ws[lk][lr] = w.x; Ws[lk + 1][lr] = w.y; Ws[lk + 2][lr] = w.z; Ws[lk + 3][lr] = w.w;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 av = *reinterpret_cast<const float4 *>(&As[k][4 * ty]);
+            const float4 wv = *reinterpret_cast<const float4 *>(&Ws[k][4 * tx]);
+            const float ar[4] = {av.x, av.y, av.z, av.w}, wr[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(ar[i], wr[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = r0 + 4 * ty + i;
+        if (b >= rows) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = o0 + 4 * tx + j;
+            if (o >= O) continue;
+            float v = acc[i][j] + bias[o];
+            if (add) v += add[(size_t)b * add_stride + o];
+            if (POST_SILU) v = silu(v);
+            out[(size_t)b * O + o] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Small-K projection C -> D (x_in / cond_to_emb, latent_si_v31.py:172), exact fp32 FMA chains over c.
 //   MODE 0 (once per sample): out = in @ W^T + bias + bias2 + mask_emb[mask]      (cond_to_emb part)
 //   MODE 1 (every evaluation): out = in @ W^T + base                              (x_in part + cached)

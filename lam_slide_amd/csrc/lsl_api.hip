@@ -208,7 +208,9 @@ void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi, hipStream_t st) {
     static const int forced = env_int("LSL_GEMM", -1);
-    const int variant = forced >= 0 ? forced : (std::is_same<Epi, EpiLinear2>::value ? 5 : 6);
+    // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
+    const bool ragged = F % 256 != 0 && (F % 256 <= 128);
+    const int variant = forced >= 0 ? forced : ragged ? 10 : (std::is_same<Epi, EpiLinear2>::value ? 5 : 6);
     static const int probe = env_int("LSL_PROBE", 0);
     GemmArgs g{W, X, F, N, K, probe};
     switch (variant) {
@@ -225,8 +227,8 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
 template <int HDP, int NW, int ITEMS, int NKT>
 void launch_attention_rows(const AttnArgs &a, hipStream_t st) {
     auto kern = k_attention_rows<HDP, NW, ITEMS, NKT>;
-    constexpr size_t lds = (size_t)ITEMS * 2 * NKT * 32 * HDP * 2;
-    static bool once = (allow_lds(kern, lds), true);
+    const size_t lds = (size_t)ITEMS * 2 * (NKT > 0 ? NKT * 32 : (a.S + 31) & ~31) * HDP * 2;
+    static bool once = (allow_lds(kern, NKT > 0 ? lds : (size_t)160 * 1024), true);
     (void)once;
     const long items = (long)a.n_seq * a.H;
     hipLaunchKernelGGL(kern, dim3((unsigned)((items + ITEMS - 1) / ITEMS)), dim3(NW * 64), lds, st, a);
@@ -236,7 +238,13 @@ template <int HDP>
 void launch_attention_t(const AttnArgs &a, hipStream_t st) {
     const int Sp = (a.S + 31) & ~31;
     static const int online = env_int("LSL_ATTN_ONLINE", 0);  // 1: force the online-softmax kernel (A/B measurements)
-    if (Sp <= 256 && !online) {  // whole score row in registers
+    if (!online && a.S <= 8) {  // one lane per (query, head), no MFMA padding
+        const long lanes = (long)a.n_seq * a.S * a.H;
+        hipLaunchKernelGGL((k_attention_tiny<HDP>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, a);
+        return;
+    }
+    if (!online && (size_t)2 * Sp * HDP * 2 <= (size_t)160 * 1024) {  // two-pass softmax, K/V of one (sequence, head) in LDS
+        if (Sp > 256) return launch_attention_rows<HDP, 8, 1, 0>(a, st);
         if (Sp <= 32) return launch_attention_rows<HDP, 4, 4, 1>(a, st);
         if (Sp <= 64) return launch_attention_rows<HDP, 4, 2, 2>(a, st);
         if (Sp <= 128) return launch_attention_rows<HDP, 4, 1, 4>(a, st);
@@ -264,6 +272,16 @@ void launch_attention_t(const AttnArgs &a, hipStream_t st) {
     }
 }
 
+template <bool PRE, bool POST>
+void launch_dense(float *out, const float *in, const float *W, const float *bias, const float *add, int rows, int I, int O,
+                  int add_stride, hipStream_t st) {
+    if (rows > 8 && I % 4 == 0)
+        hipLaunchKernelGGL((k_dense_tiled<PRE, POST>), dim3((O + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, out, in, W, bias, add, rows,
+                           I, O, add_stride);
+    else
+        hipLaunchKernelGGL((k_dense_rows<PRE, POST>), dim3((O + 3) / 4), dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride);
+}
+
 // ---- pieces of one evaluation ----------------------------------------------------------------------
 
 // conditioning vector -> all modulation tables for `rows` trajectories (latent_si_v31.py:176-178,
@@ -274,12 +292,9 @@ int run_mods(lsl_model *m, const Workspace &ws, const float *t_dev, float t_scal
     const int D = m->d.hidden;
     m->prof.begin(6, st);
     hipLaunchKernelGGL(k_time_features, dim3((rows * 128 + 255) / 256), dim3(256), 0, st, ws.tfeat, t_dev, t_scalar, w.time_freqs, rows);
-    hipLaunchKernelGGL((k_dense_rows<false, true>), dim3((D + 3) / 4), dim3(256), 0, st, ws.hid, ws.tfeat, w.time_w1, w.time_b1,
-                       (const float *)nullptr, rows, 256, D, 0);
-    hipLaunchKernelGGL((k_dense_rows<false, false>), dim3((D + 3) / 4), dim3(256), 0, st, vec_out, ws.hid, w.time_w2, w.time_b2, yemb,
-                       rows, D, D, D);
-    hipLaunchKernelGGL((k_dense_rows<true, false>), dim3((m->MODW + 3) / 4), dim3(256), 0, st, mods_out, vec_out, w.mod_w, w.mod_b,
-                       (const float *)nullptr, rows, D, m->MODW, 0);
+    launch_dense<false, true>(ws.hid, ws.tfeat, w.time_w1, w.time_b1, nullptr, rows, 256, D, 0, st);
+    launch_dense<false, false>(vec_out, ws.hid, w.time_w2, w.time_b2, yemb, rows, D, D, D, st);
+    launch_dense<true, false>(mods_out, vec_out, w.mod_w, w.mod_b, nullptr, rows, D, m->MODW, 0, st);
     m->prof.end(6, st);
     LSL_CHECK_LAUNCH("modulation");
     return 0;
@@ -289,10 +304,8 @@ int run_mods(lsl_model *m, const Workspace &ws, const float *t_dev, float t_scal
 int run_yemb(lsl_model *m, const Workspace &ws, const float *y, int rows, hipStream_t st) {
     const lsl_weights &w = m->w;
     const int D = m->d.hidden, V = m->d.vec_in_dim;
-    hipLaunchKernelGGL((k_dense_rows<false, true>), dim3((D + 3) / 4), dim3(256), 0, st, ws.hid, y, w.vec_w1, w.vec_b1,
-                       (const float *)nullptr, rows, V, D, 0);
-    hipLaunchKernelGGL((k_dense_rows<false, false>), dim3((D + 3) / 4), dim3(256), 0, st, ws.yemb, ws.hid, w.vec_w2, w.vec_b2,
-                       (const float *)nullptr, rows, D, D, 0);
+    launch_dense<false, true>(ws.hid, y, w.vec_w1, w.vec_b1, nullptr, rows, V, D, 0, st);
+    launch_dense<false, false>(ws.yemb, ws.hid, w.vec_w2, w.vec_b2, nullptr, rows, D, D, 0, st);
     LSL_CHECK_LAUNCH("vec_in");
     return 0;
 }
