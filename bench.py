@@ -154,14 +154,15 @@ def main():
     avg_ms = total_ms.value / max(1, launches.value)
     flops_per_launch = kflops_total / launches_total            # algorithmic FLOPs of one launch
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 and kflops_total else None
-    # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see profiles/), valid
-    # only when this run launches the same number of tokens per pass as the profiled run
+    # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see profiles/): measured
+    # on a 61 440-token launch of this workload; both operand and output bytes scale with the tokens of a launch (weights
+    # are < 1 % of them), so the per-token figure is scaled to this run's tokens per launch.
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
         key = {0: "linear1", 1: "linear2"}.get(args.profile_kernel)
-        if key and tj["workload"] == args.workload and tj["tokens_per_launch"] == pass_size * T * L:
-            traffic = tj[key]["bytes"]
+        if key and tj["workload"] == args.workload:
+            traffic = int(tj[key]["bytes"] / tj["tokens_per_launch"] * min(pass_size, B) * T * L)
     except (OSError, KeyError, ValueError):
         pass
     roofline = {

@@ -109,10 +109,10 @@ int default_chunk(const lsl_model *m, int B, int T, int L) {
         const int v = atoi(e);
         if (v > 0) return v < B ? v : B;
     }
-    // Measured on MI355X (profiles/r01_chunk_sweep.txt): pass size barely matters between 2 and 32 trajectories
-    // of the MD17 shape (kernels are not HBM-bound), larger is marginally faster; cap a pass at about 64 Ki tokens
-    // so the workspace stays below ~1 GiB.
-    size_t c = (size_t)65536 / ((size_t)T * L ? (size_t)T * L : 1);
+    // Measured on MI355X (profiles/r01_chunk_sweep.txt): the kernels are not helped by keeping a pass inside the
+    // 256 MiB Infinity Cache; larger passes are faster (fewer, better filled launches).  Cap a pass at 256 Ki tokens so the
+    // workspace stays at a few GiB (of 288).
+    size_t c = (size_t)262144 / ((size_t)T * L ? (size_t)T * L : 1);
     if (c < 1) c = 1;
     return (int)(c < (size_t)B ? c : (size_t)B);
 }
