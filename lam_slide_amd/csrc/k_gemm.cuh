@@ -24,6 +24,7 @@ struct GemmArgs {
     const u16 *W;  // [F][K] bf16
     const u16 *X;  // [N][K] bf16
     int F, N, K;
+    int stagger;  // persistent grids: initial delay of the second half of the workgroups, in units of 8128 cycles
     int probe;  // TIMING PROBES ONLY (results wrong): bit0 skip operand loads, bit1 skip LDS reads + MFMAs, bit2 skip epilogue
 };
 
@@ -56,7 +57,7 @@ struct GemmCfg {
 };
 
 template <int BF, int BT, int NWF, int NWT, int BK, int NS, bool PERSIST, class Epi>
-__global__ void __launch_bounds__(NWF *NWT * 64, 2) k_gemm_glds(GemmArgs g, Epi epi) {  // >= 2 waves/SIMD: at most 256 VGPRs
+__global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT / 4 : 2)) k_gemm_glds(GemmArgs g, Epi epi) {  // the whole workgroup resident, >= 2 waves/SIMD
     using Cfg = GemmCfg<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>;
     constexpr int NW = Cfg::NW, WF = Cfg::WF, WT = Cfg::WT;
     constexpr int MI = WF / 32, NJ = WT / 32;
@@ -122,6 +123,11 @@ __global__ void __launch_bounds__(NWF *NWT * 64, 2) k_gemm_glds(GemmArgs g, Epi 
     };
     char *stage = smem + Cfg::stage_base + (size_t)wave * Epi::template wave_stage_bytes<WF, WT>();
 
+    // Co-resident workgroups run the same program on equal-sized tiles and would stay in lockstep (all in their main
+    // loops together, all in their epilogues together).  g.stagger delays the second half of a persistent grid once, by
+    // about half a tile, so one workgroup's MFMA phase lines up with its neighbour's epilogue (memory) phase.
+    if (PERSIST && g.stagger > 0 && blockIdx.x >= gridDim.x / 2)
+        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     set_tile(blockIdx.x);
     prologue();
     for (int v = blockIdx.x; v < ntiles; v += PERSIST ? gridDim.x : ntiles) {
