@@ -75,10 +75,9 @@ def main():
 
     kw, T, L, cond_idx, method, skw, default_b = WORKLOADS[args.workload]
     B = args.batch or default_b
-    from oracle import latent_net  # seeded synthetic weights only (checker-side helper; no compute on the timed path)
-    sh = latent_net.NetShape(**kw)
-    params = latent_net.random_params(sh, seed=0)
+    from lam_slide_amd.synthetic import seeded_state_dict
     net = LatentSIV3(reset_parameters=False, **kw)
+    params = seeded_state_dict(net, seed=0)
     net.load_state_dict(params)
     net.to(dev)
     if args.chunk:
@@ -192,8 +191,9 @@ def main():
 
     cpu = None
     if not args.no_cpu and world == 1:
-        from oracle import harness, transport as otr
+        from oracle import harness, latent_net, transport as otr  # the checker, timed as the CPU baseline only
         import torch as th
+        sh = latent_net.NetShape(**kw)
         host_cores = os.cpu_count() or 1
         xc_c, m_c = x_cond[:1].cpu(), mask[:1].cpu()
         y_c = y[:1].cpu() if y is not None else None

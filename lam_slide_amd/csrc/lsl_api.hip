@@ -201,12 +201,14 @@ void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 
 // GEMM tiling (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
 //   (features x tokens, waves, BK x ring stages):
-//   5  256x256 8w 64x2, one tile per workgroup          6  256x256 8w 32x3, persistent workgroups + next-tile prefetch
-//   7  256x256 8w 32x3, one tile per workgroup          8  256x256 8w 32x2            10  128x128 4w 32x3
-//   15 256x256 16w 64x2 (64x64 per wave, 4 waves/SIMD: the light linear2 epilogue fits 128 VGPRs and the extra occupancy
-//      hides the load / store latencies)
-// Default (-1): 6 for linear1 (K = D is short, the heavy epilogue overlaps the next tile's loads) and 15 for linear2,
-// the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt).
+//   5  256x256  8 waves 64x2, one tile per workgroup
+//   6  256x256  8 waves 32x3, persistent workgroups + next-tile prefetch during the epilogue
+//   10 128x128  4 waves 32x3 (used when F is not a multiple of 256: D = 128 / 384 models)
+//   13 256x128  4 waves 32x2, persistent, two workgroups per CU
+//   15 256x256 16 waves 64x2 (64x64 per wave, 4 waves/SIMD: the light linear2 epilogue fits the 128-VGPR budget and the
+//      extra occupancy hides load / store latency)
+// Default (-1): 6 for linear1, 15 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
+// every variant that was tried, including the ones no longer compiled in).
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi, hipStream_t st) {
     static const int forced = env_int("LSL_GEMM", -1);
@@ -217,17 +219,11 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     static const int stagger = env_int("LSL_STAGGER", 0);
     GemmArgs g{W, X, F, N, K, stagger, probe};
     switch (variant) {
-        case 6: return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, epi, st);
-        case 7: return launch_gemm_glds<256, 256, 2, 4, 32, 3, false>(g, epi, st);
-        case 8: return launch_gemm_glds<256, 256, 2, 4, 32, 2, false>(g, epi, st);
+        case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
-        case 11: return launch_gemm_glds<256, 128, 2, 2, 32, 2, false>(g, epi, st);
-        case 12: return launch_gemm_glds<128, 256, 2, 2, 32, 2, false>(g, epi, st);
         case 13: return launch_gemm_glds<256, 128, 2, 2, 32, 2, true>(g, epi, st);
         case 15: return launch_gemm_glds<256, 256, 4, 4, 64, 2, false>(g, epi, st);
-        case 16: return launch_gemm_glds<256, 256, 4, 4, 32, 2, false>(g, epi, st);
-        case 14: return launch_gemm_glds<256, 128, 2, 2, 64, 2, true>(g, epi, st);
-        default: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
+        default: return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, epi, st);
     }
 }
 
