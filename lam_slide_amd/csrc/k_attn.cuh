@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
     const int S = a.S;
     const int nkt = NKT > 0 ? NKT : (S + 31) >> 5, Sp = nkt * 32;  // NKT = 0: key-tile count known at run time only
     const int item_local = wave / WPI, wsub = wave % WPI;
-    const long item = (long)blockIdx.x * ITEMS + item_local;
+    // heads of one sequence share 128-byte lines of the token rows: keep neighbouring (sequence, head) items on one XCD
+    const long item = (long)xcd_remap(blockIdx.x, gridDim.x) * ITEMS + item_local;
     const bool item_ok = item < (long)a.n_seq * a.H;
     const int seq = item_ok ? (int)(item / a.H) : 0, head = item_ok ? (int)(item % a.H) : 0;
     const size_t tok0 = (size_t)(seq / a.inner) * a.outer_stride + (seq % a.inner);

@@ -204,6 +204,15 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
 // linear1 epilogue: + bias; q/k heads: RMS norm * scale, RoPE (q additionally * softmax scale * log2 e);
 // v: as is; mlp: erf-GELU.  Output bf16:  qkv[n][0 .. 3*HHD)  and  z[n][HHD .. HHD+M).
 // (mmdit.py:241-248, 129-148, 85-90, 11-18)
+//
+// Two phases per slab of 64 features x 32 tokens, through wave-private LDS (fp32, 8 KiB per wave):
+//   A  the raw accumulators are written column-wise (lane = token, 4 consecutive features per 16-byte chunk);
+//   B  they are read back row-wise: 8 lanes cover one token's 64 features, a lane owns 8 consecutive features
+//      (a quarter of a 32-wide head, half of a 16-wide one), so the RoPE pairs are lane-local, the head's sum of
+//      squares is 1-2 xor-shuffles, and the result leaves as one 16-byte store per lane = whole 128-byte row
+//      segments, 8 token rows per instruction.
+// Phase B needs ~40 VGPRs and none of the accumulators of the other slabs, which is what lets the kernel run at the
+// 128-VGPR budget of 4 waves per SIMD.
 template <int HDP>
 struct EpiLinear1 {
     const float *bias;     // [F1]
@@ -217,96 +226,76 @@ struct EpiLinear1 {
     float q_premul;        // head_dim^-0.5 * log2(e), folded into q for the exp2-based softmax
 
     template <int WF, int WT>
-    static constexpr size_t wave_stage_bytes() { return (size_t)(WF < 64 ? WF : 64) * WT * 2; }  // 64-feature slab
-
-    __device__ __forceinline__ void values(const f32x16 &acc, int f0, const float2 *tab, int hf, float (&v)[16]) const {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 b = *reinterpret_cast<const float4 *>(bias + f0 + 8 * q4 + 4 * hf);
-            v[4 * q4] = acc[4 * q4] + b.x;
-            v[4 * q4 + 1] = acc[4 * q4 + 1] + b.y;
-            v[4 * q4 + 2] = acc[4 * q4 + 2] + b.z;
-            v[4 * q4 + 3] = acc[4 * q4 + 3] + b.w;
-        }
-        const int sec = f0 / HHD;  // 0 q, 1 k, 2 v, >= 3 mlp (wave-uniform: HHD is a multiple of 32)
-        if (sec < 2) {
-            const float *sc = sec == 0 ? qs : ks;
-            const float post = sec == 0 ? q_premul : 1.0f;
-            constexpr int GROUPS = 32 / HDP;  // heads per 32-feature tile
-            constexpr int RPG = 16 / GROUPS;  // registers per head
-#pragma unroll
-            for (int gi = 0; gi < GROUPS; ++gi) {
-                float ss = 0.0f;
-#pragma unroll
-                for (int e = 0; e < RPG; ++e) ss = fmaf(v[gi * RPG + e], v[gi * RPG + e], ss);
-                ss += xhalf(ss);
-                const float rr = rsqrtf(fmaf(ss, inv_hd, 1e-6f)) * post;
-#pragma unroll
-                for (int q4 = 0; q4 < RPG / 4; ++q4) {
-                    __builtin_amdgcn_sched_barrier(0);  // do not hoist the next group's table loads (VGPR budget)
-                    const int e = gi * RPG + 4 * q4;
-                    const int d = (8 * q4 + 4 * hf) & (HDP - 1);  // first of 4 consecutive channels inside the head
-                    const float4 s4 = *reinterpret_cast<const float4 *>(sc + d);
-                    const float4 cs = *reinterpret_cast<const float4 *>(tab + (d >> 1));  // (cos0, sin0, cos1, sin1)
-                    const float x0 = v[e] * rr * s4.x, x1 = v[e + 1] * rr * s4.y;
-                    const float x2 = v[e + 2] * rr * s4.z, x3 = v[e + 3] * rr * s4.w;
-                    v[e] = cs.x * x0 - cs.y * x1;
-                    v[e + 1] = cs.y * x0 + cs.x * x1;
-                    v[e + 2] = cs.z * x2 - cs.w * x3;
-                    v[e + 3] = cs.w * x2 + cs.z * x3;
-                }
-            }
-        } else if (sec >= 3) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                if ((e & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-                v[e] = gelu_fast(v[e]);
-            }
-        }
-    }
+    static constexpr size_t wave_stage_bytes() { return (size_t)64 * 32 * 4; }
 
     template <int MI, int NJ>
     __device__ __forceinline__ void run(f32x16 (&acc)[MI][NJ], char *stage, int f_wave, int n_wave, int lane, int F, int N) const {
-        constexpr int WT = NJ * 32, GI = MI < 2 ? MI : 2, CH = GI * 4;  // slab of GI*32 features: CH 16-byte chunks per row
-        constexpr int RPI = 64 / CH;                                     // token rows written per store instruction
+        static_assert(MI % 2 == 0, "feature slabs are 64 wide");
+        constexpr int CH = 16;  // 64 fp32 features = 16 chunks of 16 B per staged token row
         const int r = lane & 31, hf = lane >> 5;
-        const float2 *tab[NJ];
+        const int tr = lane >> 3, c = lane & 7;  // phase B: token row within a group of 8, 8-feature chunk
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const unsigned n = (unsigned)min(n_wave + j * 32 + r, N - 1);
-            tab[j] = rope + (size_t)((n / (unsigned)pos_div) % (unsigned)pos_mod) * (HDP / 2);
-        }
-        const int chunk = lane % CH;
-#pragma unroll
-        for (int i0 = 0; i0 < MI; i0 += GI) {
-            if (f_wave + i0 * 32 >= F) continue;  // wave-uniform
-#pragma unroll
-            for (int ii = 0; ii < GI; ++ii) {
-                const int f0 = f_wave + (i0 + ii) * 32;
-                if (f0 >= F) continue;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    __builtin_amdgcn_sched_barrier(0);  // keep one tile's temporaries live at a time (VGPR budget)
-                    float v[16];
-                    values(acc[i0 + ii][j], f0, tab[j], hf, v);
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        u32x2 pk = {pack2(v[4 * q4], v[4 * q4 + 1]), pack2(v[4 * q4 + 2], v[4 * q4 + 3])};
-                        *reinterpret_cast<u32x2 *>(stage + stage_off<CH>(j * 32 + r, 4 * ii + q4) + 8 * hf) = pk;
-                    }
+        for (int i0 = 0; i0 < MI; i0 += 2) {
+            const int fs = f_wave + i0 * 32;  // first feature of the slab
+            if (fs >= F) continue;            // wave-uniform
+            const int f = fs + 8 * c;         // this lane's 8 features in phase B
+            const bool f_ok = f < F;
+            const int sec = f / HHD;          // 0 q, 1 k, 2 v, >= 3 mlp
+            const int d = f & (HDP - 1);      // channel of the first feature inside its head (sections start on heads)
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, s0 = b0, s1 = b0;
+            if (f_ok) {
+                b0 = *reinterpret_cast<const float4 *>(bias + f);
+                b1 = *reinterpret_cast<const float4 *>(bias + f + 4);
+                if (sec < 2) {
+                    const float *sc = sec == 0 ? qs : ks;
+                    s0 = *reinterpret_cast<const float4 *>(sc + d);
+                    s1 = *reinterpret_cast<const float4 *>(sc + d + 4);
                 }
             }
-            // row-wise flush: CH lanes cover the slab of one token (16 B each), RPI tokens per instruction
-            const int f = f_wave + i0 * 32 + 8 * chunk;
-            const bool f_ok = f < F;
-            const bool to_qkv = f < 3 * HHD;
-#pragma unroll 4
-            for (int row0 = 0; row0 < WT; row0 += RPI) {
-                const int row = row0 + lane / CH, n = n_wave + row;
-                const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + stage_off<CH>(row, chunk));
-                if (f_ok && n < N) {
-                    u16 *dst = to_qkv ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
-                    *reinterpret_cast<u32x4 *>(dst) = val;
+            const float post = sec == 0 ? q_premul : 1.0f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                // phase A
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x16 &a = acc[i0 + ii][j];
+                        *reinterpret_cast<float4 *>(stage + stage_off<CH>(r, 8 * ii + 2 * q4 + hf)) =
+                            make_float4(a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]);
+                    }
+                // phase B
+#pragma unroll 2
+                for (int row0 = 0; row0 < 32; row0 += 8) {
+                    const int row = row0 + tr, n = n_wave + j * 32 + row;
+                    const float4 lo = *reinterpret_cast<const float4 *>(stage + stage_off<CH>(row, 2 * c));
+                    const float4 hi = *reinterpret_cast<const float4 *>(stage + stage_off<CH>(row, 2 * c + 1));
+                    float v[8] = {lo.x + b0.x, lo.y + b0.y, lo.z + b0.z, lo.w + b0.w, hi.x + b1.x, hi.y + b1.y, hi.z + b1.z, hi.w + b1.w};
+                    if (sec < 2) {
+                        float ss = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
+                        ss += __shfl_xor(ss, 1, 64);
+                        if (HDP == 32) ss += __shfl_xor(ss, 2, 64);
+                        const float rr = rsqrtf(fmaf(ss, inv_hd, 1e-6f)) * post;
+                        const unsigned nn = (unsigned)min(n, N - 1);
+                        const float2 *tab = rope + (size_t)((nn / (unsigned)pos_div) % (unsigned)pos_mod) * (HDP / 2) + (d >> 1);
+                        const float4 c0 = *reinterpret_cast<const float4 *>(tab), c1 = *reinterpret_cast<const float4 *>(tab + 2);
+                        const float x0 = v[0] * rr * s0.x, x1 = v[1] * rr * s0.y, x2 = v[2] * rr * s0.z, x3 = v[3] * rr * s0.w;
+                        const float x4 = v[4] * rr * s1.x, x5 = v[5] * rr * s1.y, x6 = v[6] * rr * s1.z, x7 = v[7] * rr * s1.w;
+                        v[0] = c0.x * x0 - c0.y * x1; v[1] = c0.y * x0 + c0.x * x1;
+                        v[2] = c0.z * x2 - c0.w * x3; v[3] = c0.w * x2 + c0.z * x3;
+                        v[4] = c1.x * x4 - c1.y * x5; v[5] = c1.y * x4 + c1.x * x5;
+                        v[6] = c1.z * x6 - c1.w * x7; v[7] = c1.w * x6 + c1.z * x7;
+                    } else if (sec >= 3) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+                    }
+                    if (f_ok && n < N) {
+                        const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                        u16 *dst = sec < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
+                        *reinterpret_cast<u32x4 *>(dst) = pk;
+                    }
                 }
             }
         }
