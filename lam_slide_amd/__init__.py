@@ -10,8 +10,8 @@ The compute lives in liblamslide_hip.so (include/lsl_api.h); build it with ``__g
 """
 from . import _lib
 from .latent_si import LatentSIV3
-from .sampling import SecondStageSampler, sample_sharded, setup_conditioning, shard_bounds
+from .sampling import SecondStageSampler, min_ade_fde, sample_sharded, setup_conditioning, shard_bounds
 from .transport import CreateTransport, ModelType, PathType, Sampler, SampleResult, Transport, WeightType
 
 __all__ = ["LatentSIV3", "CreateTransport", "Transport", "Sampler", "SampleResult", "ModelType", "PathType", "WeightType",
-           "SecondStageSampler", "setup_conditioning", "sample_sharded", "shard_bounds", "_lib"]
+           "SecondStageSampler", "setup_conditioning", "sample_sharded", "shard_bounds", "min_ade_fde", "_lib"]

@@ -90,6 +90,30 @@ class SecondStageSampler:
         return out
 
     @torch.no_grad()
+    def sample_latents_k(self, latents: Tensor, K: int, y: Optional[Tensor] = None, inits: Optional[Tensor] = None) -> Tensor:
+        """K samples per conditioning in ONE fused call.  The reference's test loops re-encode the identical batch and call
+        ``sample`` K times in sequence (second_stage/pedestrian.py:193-204, nba.py:205-217, md17.py:157-166); trajectories are
+        independent, so the K samples are folded into the batch: [B,...] -> [K*B,...] with the conditioning computed once.
+        inits: optional [K,B,T,L,C] initial noises.  Returns [K,B,T,L,C]; sample k equals ``sample_latents(latents, init=inits[k])``
+        bit for bit (batch independence)."""
+        B = latents.shape[0]
+        x_cond, mask = setup_conditioning(latents, self.cond_idx, self.mask_cond_mean)
+        xc = x_cond.unsqueeze(0).expand(K, *x_cond.shape).reshape(K * B, *x_cond.shape[1:]).contiguous()
+        mk = {"x_cond": xc, "x_cond_mask": mask.unsqueeze(0).expand(K, *mask.shape).reshape(K * B, *mask.shape[1:]).contiguous()}
+        if y is not None:
+            mk["y"] = y.unsqueeze(0).expand(K, *y.shape).reshape(K * B, *y.shape[1:]).contiguous()
+        if inits is None:
+            g = torch.Generator(device=latents.device).manual_seed(self.seed)
+            init = torch.randn(xc.shape, generator=g, device=latents.device, dtype=xc.dtype)
+        else:
+            init = inits.reshape(K * B, *inits.shape[2:])
+        sampler = Sampler(self.si, seed=self.seed)
+        fn = sampler.get_sample_fn(self.sampling_method, dict(self.sampling_kwargs))
+        out = fn(init, self.forward, **mk)[-1]
+        self.last_sampler = sampler
+        return out.reshape(K, B, *out.shape[1:])
+
+    @torch.no_grad()
     def sample(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Full counterpart of lightning_base.py:217-238; needs ``encode`` and ``decode``."""
         if self.encode is None or self.decode is None:
@@ -121,3 +145,12 @@ def sample_sharded(sample_fn: Callable[[Tensor, int], Tensor], latents: Tensor, 
     gathered = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(gathered, pad.contiguous(), group=group)
     return torch.cat([g[:s] for g, s in zip(gathered, sizes)], dim=0)
+
+
+@torch.no_grad()
+def min_ade_fde(trajectories: Tensor, target: Tensor) -> Tuple[Tensor, Tensor]:
+    """Best-of-K displacement errors on the device (second_stage/pedestrian.py:178-185 ``_compute_errors``).
+    trajectories: [N, K, T, D] predicted positions of N agents; target: [N, T, D].
+    Returns (ADE, FDE), each [N]: the minimum over K of the time-averaged / final-frame L2 error."""
+    err = torch.norm(trajectories - target[:, None], dim=-1)  # [N, K, T]
+    return err.mean(dim=-1).min(dim=1).values, err[..., -1].min(dim=1).values

@@ -151,3 +151,11 @@ def decode(p: Dict[str, Tensor], ds: DecoderShape, z: Tensor, entities: Tensor) 
 
 def rel_l2(a: Tensor, b: Tensor) -> float:
     return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def compute_errors(selected_traj: Tensor, all_target: Tensor) -> Tuple[Tensor, Tensor]:
+    """second_stage/pedestrian.py:178-185 (same in nba.py): best-of-K ADE / FDE.  selected_traj [N,K,T,D], all_target [N,T,D]."""
+    error = torch.norm(selected_traj - all_target[:, None], dim=-1)  # [N, K, T]
+    error_ave = error.mean(dim=-1)
+    error_final = error[..., -1]
+    return error_ave.min(dim=1).values, error_final.min(dim=1).values

@@ -212,3 +212,25 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_min_ade_fde_matches_reference_formula():
+    """Executes the reference's own `_compute_errors` (pedestrian.py:178-185, extracted with ast) against the product and the oracle.
+    /root/reference only exists in the build container, so the comparison against the source is skipped elsewhere."""
+    from lam_slide_amd import min_ade_fde
+    g = torch.Generator().manual_seed(3)
+    traj, target = torch.randn(7, 5, 12, 2, generator=g), torch.randn(7, 12, 2, generator=g)
+    a, f = min_ade_fde(traj, target)
+    oa, of = harness.compute_errors(traj, target)
+    assert torch.equal(a, oa) and torch.equal(f, of)
+    brute = torch.stack([torch.stack([(traj[n, k] - target[n]).norm(dim=-1).mean() for k in range(5)]).min() for n in range(7)])
+    assert torch.allclose(a, brute, atol=1e-6)
+    ref_file = "/root/reference/src/models/composites/second_stage/pedestrian.py"
+    if os.path.exists(ref_file):
+        import ast
+        tree = ast.parse(open(ref_file).read())
+        fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "_compute_errors")
+        ns = {"torch": torch}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), "<ref:_compute_errors>", "exec"), ns)
+        ra, rf = ns["_compute_errors"](traj, target)
+        assert torch.equal(a, ra) and torch.equal(f, rf)
