@@ -28,8 +28,11 @@ __device__ __forceinline__ u16 f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
 
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {  // one v_cvt_pk_bf16_f32 (round to nearest even, like f2bf)
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -41,6 +44,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+// value of lane ^ 1 / lane ^ 2 through DPP quad permutes (a VALU move; __shfl_xor goes through ds_bpermute and the LDS queue)
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
 
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
@@ -59,7 +70,9 @@ __device__ __forceinline__ float gelu_fast(float x) {
     p = fmaf(t, p, 0.5f * -0.284496736f);
     p = fmaf(t, p, 0.5f * 0.254829592f);
     const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * (x * x));
-    return fmaf(-ax, p * t * e, fmaxf(x, 0.0f));
+    float relu;  // fmaxf() costs a second v_max (input canonicalisation); NaN still propagates through the fma below
+    asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(x));
+    return fmaf(-ax, p * t * e, relu);
 }
 
 // Workgroup id remap so that consecutive logical tiles share an XCD's L2.  Hardware deals

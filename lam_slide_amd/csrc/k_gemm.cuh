@@ -128,6 +128,14 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
     // about half a tile, so one workgroup's MFMA phase lines up with its neighbour's epilogue (memory) phase.
     if (PERSIST && g.stagger > 0 && blockIdx.x >= gridDim.x / 2)
         for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    if (PERSIST && g.stagger < 0) {  // same, keyed on the hardware wave slot of wave 0 (HW_REG_HW_ID[3:0]) instead of the block index
+        if (tid == 0) *reinterpret_cast<volatile int *>(smem) = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1;
+        __syncthreads();
+        const int odd = *reinterpret_cast<volatile int *>(smem);
+        __syncthreads();
+        if (odd)
+            for (int i = 0; i < -g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     set_tile(blockIdx.x);
     prologue();
     for (int v = blockIdx.x; v < ntiles; v += PERSIST ? gridDim.x : ntiles) {
@@ -222,8 +230,10 @@ struct EpiLinear1 {
     u16 *z;                // [N][HHD + M]
     int HHD, M;
     int pos_div, pos_mod;  // position of token n inside its sequence: (n / pos_div) % pos_mod
+    unsigned div_magic, mod_magic;  // floor(2^32 / d) + 1 for d = pos_div, pos_mod (0 when d == 1): n / d == umulhi(n, magic) for n * d < 2^32
     float inv_hd;          // 1 / true head_dim
     float q_premul;        // head_dim^-0.5 * log2(e), folded into q for the exp2-based softmax
+    int probe;             // TIMING PROBES ONLY (results wrong): bit3 skip norm/RoPE/GELU math, bit4 skip the global stores
 
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return (size_t)64 * 32 * 4; }
@@ -240,7 +250,8 @@ struct EpiLinear1 {
             if (fs >= F) continue;            // wave-uniform
             const int f = fs + 8 * c;         // this lane's 8 features in phase B
             const bool f_ok = f < F;
-            const int sec = f / HHD;          // 0 q, 1 k, 2 v, >= 3 mlp
+            const int sec_out = f / HHD;      // 0 q, 1 k, 2 v, >= 3 mlp
+            const int sec = (probe & 8) ? 2 : sec_out;
             const int d = f & (HDP - 1);      // channel of the first feature inside its head (sections start on heads)
             float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, s0 = b0, s1 = b0;
             if (f_ok) {
@@ -275,11 +286,13 @@ struct EpiLinear1 {
                         float ss = 0.0f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
-                        ss += __shfl_xor(ss, 1, 64);
-                        if (HDP == 32) ss += __shfl_xor(ss, 2, 64);
+                        ss += quad_xor1(ss);
+                        if (HDP == 32) ss += quad_xor2(ss);
                         const float rr = rsqrtf(fmaf(ss, inv_hd, 1e-6f)) * post;
                         const unsigned nn = (unsigned)min(n, N - 1);
-                        const float2 *tab = rope + (size_t)((nn / (unsigned)pos_div) % (unsigned)pos_mod) * (HDP / 2) + (d >> 1);
+                        const unsigned n1 = div_magic ? __umulhi(nn, div_magic) : nn;
+                        const unsigned pos = mod_magic ? n1 - __umulhi(n1, mod_magic) * (unsigned)pos_mod : 0u;
+                        const float2 *tab = rope + (size_t)pos * (HDP / 2) + (d >> 1);
                         const float4 c0 = *reinterpret_cast<const float4 *>(tab), c1 = *reinterpret_cast<const float4 *>(tab + 2);
                         const float x0 = v[0] * rr * s0.x, x1 = v[1] * rr * s0.y, x2 = v[2] * rr * s0.z, x3 = v[3] * rr * s0.w;
                         const float x4 = v[4] * rr * s1.x, x5 = v[5] * rr * s1.y, x6 = v[6] * rr * s1.z, x7 = v[7] * rr * s1.w;
@@ -291,13 +304,108 @@ struct EpiLinear1 {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
                     }
-                    if (f_ok && n < N) {
+                    if (f_ok && n < N && !(probe & 16)) {
                         const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                        u16 *dst = sec < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
+                        u16 *dst = sec_out < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
                         *reinterpret_cast<u32x4 *>(dst) = pk;
                     }
                 }
             }
+        }
+    }
+    // ---- the same epilogue as 16 software-pipelined pieces of a 128-feature x 64-token wave tile (k_gemm_pp.cuh), where the
+    // epilogue runs on ONE wave per SIMD and nothing but the wave's own instruction stream can hide latency.
+    // Piece C = rows 16 (C & 1) .. +15 of the 32 x 32 accumulator tile [i = C >> 2][j = (C >> 1) & 1].  The tile is transposed
+    // through 4 KiB of wave-private LDS (fp32, layout = swz_bk<64>: 32 token rows x 8 chunks of 4 features); in phase B a lane
+    // owns 8 consecutive features of one token (4 lanes = one 32-wide head or two 16-wide ones: the sum of squares is 1-2
+    // DPP quad exchanges), 16 token rows per instruction.  Everything piece C+1 needs from memory (its LDS rows, its RoPE
+    // row, bias / scales when the feature tile changes) is requested while piece C computes: `Pipe` carries it.
+    struct Pipe {
+        float4 lo, hi;          // staged sums of the 8 features
+        float4 c0, c1;          // RoPE (cos, sin) of the 4 pairs
+        float4 b0, b1, s0, s1;  // bias, q/k scale
+    };
+    static constexpr int pieces = 16;
+    static constexpr size_t pp_stage_bytes = 4096;
+
+    template <int C>
+    __device__ __forceinline__ void fetch(f32x16 (&acc)[4][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
+        constexpr int i = C >> 2, j = (C >> 1) & 1, hb = C & 1;
+        const int r = lane & 31, hf = lane >> 5, tr = lane >> 2, c = lane & 3;
+        const int f = f_wave + i * 32 + 8 * c;
+        const int sec = (probe & 8) ? 2 : (f >= HHD) + (f >= 2 * HHD) + (f >= 3 * HHD);
+        const int d = f & (HDP - 1);
+        // every load below is unconditional (addresses clamped into the tables, unused values ignored by piece<C>): a load
+        // inside a divergent branch gets its s_waitcnt at the end of that branch, i.e. right here instead of one piece later
+        if (C % 4 == 0) {  // new feature tile
+            const int fc = min(f, F - 8);
+            k.b0 = *reinterpret_cast<const float4 *>(bias + fc);
+            k.b1 = *reinterpret_cast<const float4 *>(bias + fc + 4);
+            // both scale vectors, selected by value (a per-lane select of the two POINTERS becomes a dependent load of the pointer)
+            const float4 q0 = *reinterpret_cast<const float4 *>(qs + d), q1 = *reinterpret_cast<const float4 *>(qs + d + 4);
+            const float4 k0 = *reinterpret_cast<const float4 *>(ks + d), k1 = *reinterpret_cast<const float4 *>(ks + d + 4);
+            const bool isk = sec == 1;
+            k.s0 = make_float4(isk ? k0.x : q0.x, isk ? k0.y : q0.y, isk ? k0.z : q0.z, isk ? k0.w : q0.w);
+            k.s1 = make_float4(isk ? k1.x : q1.x, isk ? k1.y : q1.y, isk ? k1.z : q1.z, isk ? k1.w : q1.w);
+        }
+        {
+            const unsigned nn = (unsigned)min(n_wave + j * 32 + 16 * hb + tr, N - 1);
+            const unsigned n1 = div_magic ? __umulhi(nn, div_magic) : nn;
+            const unsigned pos = mod_magic ? n1 - __umulhi(n1, mod_magic) * (unsigned)pos_mod : 0u;
+            const float2 *tab = rope + (size_t)pos * (HDP / 2) + (d >> 1);
+            k.c0 = *reinterpret_cast<const float4 *>(tab);
+            k.c1 = *reinterpret_cast<const float4 *>(tab + 2);
+        }
+        if (hb == 0) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x16 &a = acc[i][j];
+                *reinterpret_cast<float4 *>(stage + swz_bk<64>(r, 2 * q4 + hf)) = make_float4(a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]);
+            }
+        }
+        const int row = 16 * hb + tr;
+        k.lo = *reinterpret_cast<const float4 *>(stage + swz_bk<64>(row, 2 * c));
+        k.hi = *reinterpret_cast<const float4 *>(stage + swz_bk<64>(row, 2 * c + 1));
+    }
+
+    template <int C>
+    __device__ __forceinline__ void piece(f32x16 (&acc)[4][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
+        constexpr int i = C >> 2, j = (C >> 1) & 1, hb = C & 1;
+        const int tr = lane >> 2, c = lane & 3;
+        const int f = f_wave + i * 32 + 8 * c;
+        const bool f_ok = f < F;
+        const int sec_out = (f >= HHD) + (f >= 2 * HHD) + (f >= 3 * HHD);  // 0 q, 1 k, 2 v, 3 mlp
+        const int sec = (probe & 8) ? 2 : sec_out;
+        const int n = n_wave + j * 32 + 16 * hb + tr;
+        float v[8] = {k.lo.x + k.b0.x, k.lo.y + k.b0.y, k.lo.z + k.b0.z, k.lo.w + k.b0.w,
+                      k.hi.x + k.b1.x, k.hi.y + k.b1.y, k.hi.z + k.b1.z, k.hi.w + k.b1.w};
+        const float4 c0 = k.c0, c1 = k.c1, s0 = k.s0, s1 = k.s1;
+        if (C + 1 < 16) fetch<(C + 1) & 15>(acc, stage, f_wave, n_wave, lane, F, N, k);
+        if (sec < 2) {
+            const float post = sec == 0 ? q_premul : 1.0f;
+            float ss = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
+            ss += quad_xor1(ss);
+            if (HDP == 32) ss += quad_xor2(ss);
+            const float rr = rsqrtf(fmaf(ss, inv_hd, 1e-6f)) * post;
+            const float x0 = v[0] * rr * s0.x, x1 = v[1] * rr * s0.y, x2 = v[2] * rr * s0.z, x3 = v[3] * rr * s0.w;
+            const float x4 = v[4] * rr * s1.x, x5 = v[5] * rr * s1.y, x6 = v[6] * rr * s1.z, x7 = v[7] * rr * s1.w;
+            v[0] = c0.x * x0 - c0.y * x1; v[1] = c0.y * x0 + c0.x * x1;
+            v[2] = c0.z * x2 - c0.w * x3; v[3] = c0.w * x2 + c0.z * x3;
+            v[4] = c1.x * x4 - c1.y * x5; v[5] = c1.y * x4 + c1.x * x5;
+            v[6] = c1.z * x6 - c1.w * x7; v[7] = c1.w * x6 + c1.z * x7;
+        } else if (sec >= 3) {  // two groups of 4: bounds the temporaries (the role runs beside 128 accumulator VGPRs)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 4; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        }
+        if (f_ok && n < N && !(probe & 16)) {
+            const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            u16 *dst = sec_out < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
+            *reinterpret_cast<u32x4 *>(dst) = pk;
         }
     }
 };
@@ -308,6 +416,8 @@ struct EpiLinear2 {
     const float *gate;  // mods + gate offset, row stride mod_stride
     float *h;           // [N][D]
     int D, mod_stride, tokens_per_traj;
+    int probe;  // unused (same launcher as EpiLinear1)
+    unsigned tpt_magic;  // floor(2^32 / tokens_per_traj) + 1 (0 when tokens_per_traj == 1): n / tokens_per_traj by multiply-high
 
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return (size_t)32 * WT * 4; }  // one 32-feature slab of the wave tile
@@ -347,6 +457,61 @@ struct EpiLinear2 {
                     *reinterpret_cast<float4 *>(hp) = hv;
                 }
             }
+        }
+    }
+    // ---- 16 software-pipelined pieces of a 128-feature x 64-token wave tile (k_gemm_pp.cuh; see EpiLinear1::Pipe): piece C =
+    // rows 16 (C & 1) .. +15 of the accumulator tile [i = C >> 2][j = (C >> 1) & 1], staged through 4 KiB of LDS; a lane owns 4
+    // features of one token, 8 token rows per instruction, two instructions per piece.  The h rows of piece C+1 are requested
+    // while piece C computes.
+    struct Pipe {
+        float4 a[2], hv[2], gt[2], b;
+    };
+    static constexpr int pieces = 16;
+    static constexpr size_t pp_stage_bytes = 4096;
+
+    template <int C>
+    __device__ __forceinline__ void fetch(f32x16 (&acc)[4][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
+        constexpr int i = C >> 2, j = (C >> 1) & 1, hb = C & 1;
+        const int r = lane & 31, hf = lane >> 5, chunk = lane & 7;
+        const int f = f_wave + i * 32 + 4 * chunk;
+        const int fc = min(f, F - 4);  // unconditional loads from clamped addresses (see EpiLinear1::fetch)
+        if (C % 4 == 0) k.b = *reinterpret_cast<const float4 *>(bias + fc);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int n = min(n_wave + j * 32 + 16 * hb + 8 * it + (lane >> 3), N - 1);
+            const unsigned traj = tpt_magic ? __umulhi((unsigned)n, tpt_magic) : (unsigned)n;
+            k.gt[it] = *reinterpret_cast<const float4 *>(gate + (size_t)traj * mod_stride + fc);
+            k.hv[it] = *reinterpret_cast<const float4 *>(h + (size_t)n * D + fc);
+        }
+        if (hb == 0) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x16 &a = acc[i][j];
+                *reinterpret_cast<float4 *>(stage + swz_bk<64>(r, 2 * q4 + hf)) = make_float4(a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) k.a[it] = *reinterpret_cast<const float4 *>(stage + swz_bk<64>(16 * hb + 8 * it + (lane >> 3), chunk));
+    }
+
+    template <int C>
+    __device__ __forceinline__ void piece(f32x16 (&acc)[4][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
+        constexpr int i = C >> 2, j = (C >> 1) & 1, hb = C & 1;
+        const int chunk = lane & 7;
+        const int f = f_wave + i * 32 + 4 * chunk;
+        float4 out[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            out[it].x = fmaf(k.gt[it].x, k.a[it].x + k.b.x, k.hv[it].x);
+            out[it].y = fmaf(k.gt[it].y, k.a[it].y + k.b.y, k.hv[it].y);
+            out[it].z = fmaf(k.gt[it].z, k.a[it].z + k.b.z, k.hv[it].z);
+            out[it].w = fmaf(k.gt[it].w, k.a[it].w + k.b.w, k.hv[it].w);
+        }
+        if (C + 1 < 16) fetch<(C + 1) & 15>(acc, stage, f_wave, n_wave, lane, F, N, k);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int n = n_wave + j * 32 + 16 * hb + 8 * it + (lane >> 3);
+            if (f < F && n < N) *reinterpret_cast<float4 *>(h + (size_t)n * D + f) = out[it];
         }
     }
 };

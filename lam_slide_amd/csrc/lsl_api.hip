@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "k_attn.cuh"
-#include "k_gemm.cuh"
+#include "k_gemm_pp.cuh"
 #include "k_small.cuh"
 
 namespace {
@@ -199,6 +199,31 @@ void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWF * NWT * 64), lds, st, g, epi);
 }
 
+template <int BK, int NS, int NB, class Epi>
+void launch_gemm_pp_t(const GemmArgs &g, const Epi &epi, hipStream_t st) {
+    auto kern = k_gemm_pp<BK, NS, NB, Epi>;
+    constexpr size_t lds = GemmPPCfg<BK, NS, Epi>::lds_bytes;
+    static bool once = (allow_lds(kern, lds), true);
+    (void)once;
+    const int tiles = ((g.N + 255) / 256) * ((g.F + 127) / 128);
+    int grid = device_cus();
+    grid -= grid % 8;
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g, epi);
+}
+
+// ping-pong halves (k_gemm_pp.cuh); false when the shape is outside what the schedule covers
+template <int BK, int NS, class Epi>
+bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
+    if (g.K % BK != 0 || g.F % 32 != 0) return false;
+    const int E = g.K / BK - (NS - 1);  // intervals that carry epilogue pieces
+    if (E < 1 || E > 64) return false;
+    if (E <= 16) launch_gemm_pp_t<BK, NS, 1>(g, epi, st);
+    else if (E <= 32) launch_gemm_pp_t<BK, NS, 2>(g, epi, st);
+    else launch_gemm_pp_t<BK, NS, 4>(g, epi, st);
+    return true;
+}
+
 // GEMM tiling (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
 //   (features x tokens, waves, BK x ring stages):
 //   5  256x256  8 waves 64x2, one tile per workgroup
@@ -210,7 +235,7 @@ void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 // Default (-1): 6 for linear1, 15 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
 // every variant that was tried, including the ones no longer compiled in).
 template <class Epi>
-void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi, hipStream_t st) {
+void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi_in, hipStream_t st, int hhd = 32) {
     static const int forced = env_int("LSL_GEMM", -1);
     // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
@@ -218,6 +243,12 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     static const int probe = env_int("LSL_PROBE", 0);
     static const int stagger = env_int("LSL_STAGGER", 0);
     GemmArgs g{W, X, F, N, K, stagger, probe};
+    Epi epi = epi_in;
+    epi.probe = probe;
+    const bool pp_ok = !std::is_same<Epi, EpiLinear2>::value ? hhd % 32 == 0 : true;  // linear1 sections start on 32-feature tiles
+    if (variant == 20 && pp_ok && launch_gemm_pp<32, 4>(g, epi, st)) return;
+    if (variant == 21 && pp_ok && launch_gemm_pp<64, 2>(g, epi, st)) return;
+    if (variant == 22 && pp_ok && launch_gemm_pp<64, 3>(g, epi, st)) return;
     switch (variant) {
         case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
@@ -278,7 +309,9 @@ void launch_attention_t(const AttnArgs &a, hipStream_t st) {
 template <bool PRE, bool POST>
 void launch_dense(float *out, const float *in, const float *W, const float *bias, const float *add, int rows, int I, int O,
                   int add_stride, hipStream_t st) {
-    if (rows > 8 && I % 4 == 0)
+    // the choice must not depend on `rows`: the two kernels sum k in different orders, and a trajectory's result has to be
+    // the same bits whatever batch it is sampled in (K-sample batching, sharding, pass size)
+    if (I % 4 == 0)
         hipLaunchKernelGGL((k_dense_tiled<PRE, POST>), dim3((O + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, out, in, W, bias, add, rows,
                            I, O, add_stride);
     else
@@ -332,14 +365,19 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     m->prof.begin(0, st);
 
     const float premul = (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
+    // position of token n along the attended axis = (n / pdiv) % pmod, done with multiply-high in the epilogue: exact while
+    // n * d < 2^32, and n < 2^18 (pass size) with d <= T or L
+    const int pdiv = temporal ? L : 1, pmod = temporal ? T : L;
+    auto magic_of = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };
+    if ((unsigned long long)n * (unsigned)std::max(pdiv, pmod) >= (1ull << 32)) return fail(-3, "pass too large for the position arithmetic");
     if (d.head_dim_pad == 32) {
         EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
-                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul};
-        launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st);
+                         pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 0};
+        launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st, m->HHD);
     } else {
         EpiLinear1<16> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
-                         temporal ? L : 1, temporal ? T : L, 1.0f / d.head_dim, premul};
-        launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st);
+                         pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 0};
+        launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st, m->HHD);
     }
     m->prof.end(0, st);
     AttnArgs aa;
@@ -359,7 +397,8 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     m->prof.end(2, st);
 
     m->prof.begin(1, st);
-    EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L};
+    if ((unsigned long long)n * (unsigned)(T * L) >= (1ull << 32)) return fail(-3, "pass too large for the trajectory arithmetic");
+    EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L, 0, magic_of(T * L)};
     launch_gemm((const u16 *)bw.w2, ws.z, D, n, m->K2, e2, st);
     m->prof.end(1, st);
     LSL_CHECK_LAUNCH("block");
