@@ -146,6 +146,54 @@ int lsl_debug_mods(lsl_model *m, const float *t, const float *y, int32_t B, floa
 int lsl_profile_enable(lsl_model *m, int32_t kernel, int32_t max_launches);
 int lsl_profile_read(lsl_model *m, double *total_ms, int32_t *launches);
 
+/* ------------------------------------------------------------------------------------------------
+ * Frozen stage-1 decode of the sampled latents: the step right after the sampler and the
+ * second half of the parity metric ("decoded coordinates").  Stands in for
+ *   first_stage.decode(latents, entities) = Decoder(post_quant(latents), entities)
+ *   (models/composites/lightning_base.py:28-31,42-44; models/components/decoder.py:12-102;
+ *    blocks: modules/torch_modules.py:104-264; entity table: modules/entity_embeddings.py:7-33).
+ * fp32 throughout.  One block = PreNorm(Attention) + residual, PreNorm(FeedForward(dim)) + residual. */
+typedef struct lsl_dec_block {
+    const float *ln_w, *ln_b;        /* attn.norm                                  [dim]                  */
+    const float *lnc_w, *lnc_b;      /* attn.norm_context (cross-attention blocks) [context_dim], else NULL */
+    const float *w_q;                /* self: attn.fn.to_qkv.weight [3*inner, dim]; cross: attn.fn.to_q.weight [inner, dim] */
+    const float *w_kv;               /* cross: attn.fn.to_kv.weight [2*inner, context_dim]; self: NULL    */
+    const float *w_out, *b_out;      /* attn.fn.to_out [dim, inner], [dim]                                */
+    const float *q_scale, *k_scale;  /* attn.fn.norm.{query,key}_norm.scale [dim_head], NULL without qk_norm */
+    const float *ff_ln_w, *ff_ln_b;  /* ff.norm                                                           */
+    const float *ff_w1, *ff_b1;      /* ff.fn.net.0.0 [dim, dim]                                          */
+    const float *ff_w2, *ff_b2;      /* ff.fn.net.1   [dim, dim]                                          */
+} lsl_dec_block;
+
+typedef struct lsl_decoder_desc {    /* Decoder.__init__ arguments (decoder.py:14-29) + post_quant input width */
+    int32_t in_dim;                  /* C of the sampled latents (post_quant = LayerNorm(C, no affine) + Linear(C, dim_latent)) */
+    int32_t dim_latent, dim_query, dim_emb, n_entities;
+    int32_t heads_latent, dim_head_latent, heads_cross, dim_head_cross;
+    int32_t num_block_attn, num_block_cross;
+    int32_t act;                     /* 1 = erf GELU (src.modules.torch_modules.GELU), 2 = nn.GELU(approximate="tanh") */
+    int32_t out_dim;                 /* width of the decoded output head (3 for "pos")                    */
+} lsl_decoder_desc;
+
+typedef struct lsl_decoder_weights {
+    const float *pq_w, *pq_b;        /* post_quant.1 [dim_latent, C], [dim_latent]                        */
+    const float *table;              /* decoder.entity_embedding.embedding.weight [n_entities, dim_emb], rows ALREADY clipped to
+                                        max_norm (nn.Embedding(max_norm=1) renormalises looked-up rows at forward time)      */
+    const float *qm_w, *qm_b;        /* decoder.query_mlp.1 [dim_query, dim_emb]                          */
+    const lsl_dec_block *self_blocks;   /* HOST array [num_block_attn]  decoder.self_attn_blocks.i       */
+    const lsl_dec_block *cross_blocks;  /* HOST array [num_block_cross] decoder.cross_attn_blocks.i      */
+    lsl_dec_block out_block;            /* decoder.output_block (queries attend to the latents)          */
+    const float *head_w1, *head_b1;  /* decoder.output_layers.<name>.0 [dim_query, dim_query]             */
+    const float *head_w2, *head_b2;  /* decoder.output_layers.<name>.2 [out_dim, dim_query]               */
+} lsl_decoder_weights;
+
+typedef struct lsl_decoder lsl_decoder;
+int lsl_decoder_create(const lsl_decoder_desc *desc, const lsl_decoder_weights *w, lsl_decoder **out);
+void lsl_decoder_destroy(lsl_decoder *d);
+size_t lsl_decode_workspace_bytes(const lsl_decoder *d, int32_t frames, int32_t L, int32_t A);
+/* z: device [frames, L, C] latents; entities: device [frames, A] int64; out: device [frames, A, out_dim]. */
+int lsl_decode(lsl_decoder *d, const float *z, const int64_t *entities, int32_t frames, int32_t L, int32_t A, float *out,
+               void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,12 +6,14 @@ Public surface (mirrors the reference's for this path only):
                                    <- src.modules.transport
   SecondStageSampler, setup_conditioning, sample_sharded
                                    <- SecondStageCondLightningBase.{sample, setup_conditioning} + batch sharding
+  Stage1Decoder                    <- first_stage.decode = Decoder(post_quant(latents), entities) (frozen, after the sampler)
 The compute lives in liblamslide_hip.so (include/lsl_api.h); build it with ``__graft_entry__.build()``.
 """
 from . import _lib
+from .decoder import Stage1Decoder
 from .latent_si import LatentSIV3
 from .sampling import SecondStageSampler, min_ade_fde, sample_sharded, setup_conditioning, shard_bounds
 from .transport import CreateTransport, ModelType, PathType, Sampler, SampleResult, Transport, WeightType
 
 __all__ = ["LatentSIV3", "CreateTransport", "Transport", "Sampler", "SampleResult", "ModelType", "PathType", "WeightType",
-           "SecondStageSampler", "setup_conditioning", "sample_sharded", "shard_bounds", "min_ade_fde", "_lib"]
+           "SecondStageSampler", "setup_conditioning", "sample_sharded", "shard_bounds", "min_ade_fde", "Stage1Decoder", "_lib"]

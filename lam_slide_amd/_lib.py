@@ -21,6 +21,7 @@ EXPORTED = (
     "lsl_version", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
     "lsl_model_set_chunk", "lsl_pass_size", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_debug_block", "lsl_debug_mods",
     "lsl_profile_enable", "lsl_profile_read",
+    "lsl_decoder_create", "lsl_decoder_destroy", "lsl_decode_workspace_bytes", "lsl_decode",
 )
 
 
@@ -42,6 +43,22 @@ class Weights(C.Structure):
 class IO(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_cond", C.c_void_p), ("mask", C.c_void_p), ("y", C.c_void_p), ("t", C.c_void_p),
                 ("out", C.c_void_p), ("B", C.c_int32), ("T", C.c_int32), ("L", C.c_int32)]
+
+
+class DecBlock(C.Structure):  # lsl_dec_block
+    _fields_ = [(n, C.c_void_p) for n in ("ln_w", "ln_b", "lnc_w", "lnc_b", "w_q", "w_kv", "w_out", "b_out", "q_scale", "k_scale",
+                                          "ff_ln_w", "ff_ln_b", "ff_w1", "ff_b1", "ff_w2", "ff_b2")]
+
+
+class DecoderDesc(C.Structure):  # lsl_decoder_desc
+    _fields_ = [(n, C.c_int32) for n in ("in_dim", "dim_latent", "dim_query", "dim_emb", "n_entities", "heads_latent", "dim_head_latent",
+                                         "heads_cross", "dim_head_cross", "num_block_attn", "num_block_cross", "act", "out_dim")]
+
+
+class DecoderWeights(C.Structure):  # lsl_decoder_weights
+    _fields_ = [("pq_w", C.c_void_p), ("pq_b", C.c_void_p), ("table", C.c_void_p), ("qm_w", C.c_void_p), ("qm_b", C.c_void_p),
+                ("self_blocks", C.POINTER(DecBlock)), ("cross_blocks", C.POINTER(DecBlock)), ("out_block", DecBlock),
+                ("head_w1", C.c_void_p), ("head_b1", C.c_void_p), ("head_w2", C.c_void_p), ("head_b2", C.c_void_p)]
 
 
 class Step(C.Structure):
@@ -96,6 +113,13 @@ def load() -> C.CDLL:
                                    C.c_void_p]
     lib.lsl_profile_enable.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.lsl_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    lib.lsl_decoder_create.argtypes = [C.POINTER(DecoderDesc), C.POINTER(DecoderWeights), C.POINTER(C.c_void_p)]
+    lib.lsl_decoder_destroy.argtypes = [C.c_void_p]
+    lib.lsl_decoder_destroy.restype = None
+    lib.lsl_decode_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.lsl_decode_workspace_bytes.restype = C.c_size_t
+    lib.lsl_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                               C.c_void_p]
     if lib.lsl_version() != 1:
         raise RuntimeError("liblamslide_hip.so version mismatch")
     _lib = lib

@@ -462,6 +462,8 @@ int check_call(const lsl_model *m, const lsl_io *io, size_t ws_bytes, void *ws, 
 
 }  // namespace
 
+#include "decode_host.cuh"
+
 extern "C" {
 
 int lsl_version(void) { return LSL_VERSION; }
@@ -631,6 +633,62 @@ int lsl_debug_mods(lsl_model *m, const float *t, const float *y, int32_t B, floa
         if (int rc = run_yemb(m, ws, y, B, st)) return rc;
     }
     return run_mods(m, ws, t, 0.0f, y ? ws.yemb : nullptr, B, vec_out, mods_out, st);
+}
+
+int lsl_decoder_create(const lsl_decoder_desc *desc, const lsl_decoder_weights *w, lsl_decoder **out) {
+    if (!desc || !w || !out) return fail(-1, "null decoder argument");
+    const lsl_decoder_desc &d = *desc;
+    if (d.in_dim % 4 || d.dim_latent % 4 || d.dim_query % 4 || d.dim_emb % 4 || (d.heads_latent * d.dim_head_latent) % 4 ||
+        (d.heads_cross * d.dim_head_cross) % 4)
+        return fail(-3, "decoder widths must be multiples of 4");
+    if (d.dim_head_latent > 64 || d.dim_head_cross > 64 || d.dim_head_latent < 1 || d.dim_head_cross < 1) return fail(-3, "decoder dim_head must be 1..64");
+    if (d.act != 1 && d.act != 2) return fail(-3, "decoder activation must be 1 (erf GELU) or 2 (tanh GELU)");
+    if (d.num_block_attn < 0 || d.num_block_cross < 0 || d.out_dim < 1 || d.n_entities < 1) return fail(-3, "bad decoder description");
+    lsl_decoder *dec = new lsl_decoder();
+    dec->d = d;
+    dec->w = *w;
+    if (d.num_block_attn) dec->self_blocks.assign(w->self_blocks, w->self_blocks + d.num_block_attn);
+    if (d.num_block_cross) dec->cross_blocks.assign(w->cross_blocks, w->cross_blocks + d.num_block_cross);
+    dec->w.self_blocks = dec->self_blocks.data();
+    dec->w.cross_blocks = dec->cross_blocks.data();
+    *out = dec;
+    return 0;
+}
+
+void lsl_decoder_destroy(lsl_decoder *d) { delete d; }
+
+size_t lsl_decode_workspace_bytes(const lsl_decoder *d, int32_t frames, int32_t L, int32_t A) {
+    if (!d || frames <= 0 || L <= 0 || A <= 0) return 0;
+    return dec_carve(d->d, frames, L, A, nullptr, nullptr);
+}
+
+// Decoder.forward (decoder.py:88-102) after post_quant (lightning_base.py:28-31,42-44)
+int lsl_decode(lsl_decoder *dec, const float *z, const int64_t *entities, int32_t frames, int32_t L, int32_t A, float *out, void *workspace,
+               size_t workspace_bytes, void *stream) {
+    if (!dec || !z || !entities || !out) return fail(-1, "null decode argument");
+    if (frames <= 0 || L <= 0 || A <= 0) return fail(-3, "decode: empty input");
+    const lsl_decoder_desc &d = dec->d;
+    const lsl_decoder_weights &w = dec->w;
+    if (workspace_bytes < dec_carve(d, frames, L, A, nullptr, nullptr) || !workspace) return fail(-4, "decode workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    DecWs ws;
+    dec_carve(d, frames, L, A, (char *)workspace, &ws);
+    const int nl = frames * L, na = frames * A;
+    // post_quant: LayerNorm(C, elementwise_affine=False) then Linear(C, dim_latent)
+    dec_ln(ws.xn, z, nullptr, nullptr, nl, d.in_dim, st);
+    dec_dense(0, ws.lat, ws.xn, w.pq_w, w.pq_b, nullptr, nl, d.in_dim, d.dim_latent, st);
+    // queries = query_mlp(entity_embedding(entities))   (dropout is identity in eval)
+    hipLaunchKernelGGL(k_dec_gather, dim3((na + 3) / 4), dim3(256), 0, st, ws.xn, w.table, entities, na, d.dim_emb, d.n_entities);
+    dec_dense(0, ws.q, ws.xn, w.qm_w, w.qm_b, nullptr, na, d.dim_emb, d.dim_query, st);
+    for (int i = 0; i < d.num_block_attn; ++i)
+        if (int rc = dec_block(w.self_blocks[i], ws.lat, L, d.dim_latent, nullptr, 0, 0, d.heads_latent, d.dim_head_latent, d.act, frames, ws, st)) return rc;
+    for (int i = 0; i < d.num_block_cross; ++i)
+        if (int rc = dec_block(w.cross_blocks[i], ws.lat, L, d.dim_latent, ws.q, A, d.dim_query, d.heads_cross, d.dim_head_cross, d.act, frames, ws, st)) return rc;
+    if (int rc = dec_block(w.out_block, ws.q, A, d.dim_query, ws.lat, L, d.dim_latent, d.heads_cross, d.dim_head_cross, d.act, frames, ws, st)) return rc;
+    dec_dense(d.act, ws.hid, ws.q, w.head_w1, w.head_b1, nullptr, na, d.dim_query, d.dim_query, st);
+    dec_dense(0, out, ws.hid, w.head_w2, w.head_b2, nullptr, na, d.dim_query, d.out_dim, st);
+    LSL_CHECK_LAUNCH("lsl_decode");
+    return 0;
 }
 
 }  // extern "C"

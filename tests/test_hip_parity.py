@@ -328,3 +328,43 @@ def test_k_sample_batching_equals_sequential_calls(dev):
     assert drv.last_sampler.last_path == "fused" and batched.shape == (4, 3, 20, 2, 32)
     for k in range(4):
         assert torch.equal(batched[k], drv.sample_latents(lat, y=y, init=inits[k]))
+
+
+def test_stage1_decode_against_reference_positions(golden, dev):
+    """post_quant + Decoder on the HIP path against positions produced by the reference's own Decoder module
+    (tests/golden/f6_decode.npz; the entity table holds rows above unit norm, so the max_norm clipping is exercised)."""
+    from lam_slide_amd import Stage1Decoder
+    d = golden("f6_decode.npz")
+    dec = Stage1Decoder(d.group("p"), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16, act="gelu_erf")
+    pos = dec.decode(d["z"].to(dev), d["entities"].to(dev)).cpu()
+    err = rel_l2(pos, d["pos"])
+    print(f"stage-1 decode rel L2 {err:.3e}")
+    assert err < 1e-5
+    # frames are independent: any subset decodes to the same bits
+    part = dec.decode(d["z"][1:3].to(dev), d["entities"][1:3].to(dev)).cpu()
+    assert torch.equal(part, pos[1:3])
+    with pytest.raises(RuntimeError):
+        dec.decode(d["z"], d["entities"])
+
+
+def test_sample_then_decode_on_device(golden, dev):
+    """The whole tail of SecondStageCondLightningBase.sample (lightning_base.py:230-238) on the device: fused sampler, then the
+    HIP decoder; decoded coordinates against the reference latents decoded by the oracle must stay within 1e-3."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler, Stage1Decoder
+    from oracle import harness, latent_net
+    f = golden("f4_cfg1.npz")
+    sh = shape_from(f.group("shape"))
+    net = build_net(sh, latent_net.random_params(sh, seed=int(f["weight_seed"])), dev)
+    lat = torch.randn(1, 30, 192, 32, generator=torch.Generator().manual_seed(int(f["latent_seed"])))
+    init = torch.randn(1, 30, 192, 32, generator=torch.Generator().manual_seed(int(f["init_seed"])))
+    d = golden("f6_decode.npz")
+    dec = Stage1Decoder(d.group("p"), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16, act="gelu_erf")
+    drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=tuple(f["cond_idx"].tolist()), mask_cond_mean=True,
+                             sampling_kwargs={"sampling_method": "euler", "num_steps": int(f["num_steps"])}, decode=dec)
+    final = drv.sample_latents(lat.to(dev), init=init.to(dev))
+    ent = torch.arange(21)[None].expand(30, 21)
+    pos = dec.decode(final[0], ent.to(dev)).cpu()
+    want = harness.decode(d.group("p"), harness.DecoderShape(), f["final"][0], ent)
+    err = rel_l2(pos, want)
+    print(f"sample + decode on device: decoded coordinates rel L2 {err:.3e}")
+    assert err < 1e-3

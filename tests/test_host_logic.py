@@ -234,3 +234,27 @@ def test_min_ade_fde_matches_reference_formula():
         exec(compile(ast.Module(body=[fn], type_ignores=[]), "<ref:_compute_errors>", "exec"), ns)
         ra, rf = ns["_compute_errors"](traj, target)
         assert torch.equal(a, ra) and torch.equal(f, rf)
+
+
+def test_stage1_decoder_packing_on_cpu(golden):
+    """Host logic of the decoder wrapper: shapes read off the reference-named state dict, max_norm clipping done once at load
+    (same formula as the oracle / torch embedding_renorm_), loud failure without a GPU."""
+    from lam_slide_amd import Stage1Decoder
+    from lam_slide_amd.decoder import renorm_table
+    d = golden("f6_decode.npz")
+    p = d.group("p")
+    dec = Stage1Decoder(p, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+    assert (dec.in_dim, dec.dim_latent, dec.dim_query, dec.dim_emb, dec.n_entities, dec.out_dim) == (32, 32, 128, 128, 32, 3)
+    assert (dec.num_block_attn, dec.num_block_cross, dec.qk_norm) == (1, 0, True)
+    table = p["decoder.entity_embedding.embedding.weight"]
+    clipped = renorm_table(table, 1.0)
+    norms = table.norm(dim=-1, keepdim=True)
+    # torch's embedding_renorm_ multiplies by max_norm / (norm + 1e-7); the oracle divides: equal to an ulp
+    assert torch.allclose(clipped, torch.where(norms > 1.0, table / (norms + 1e-7), table), rtol=3e-7, atol=0) and float(clipped.norm(dim=-1).max()) <= 1.0 + 1e-6
+    assert (norms > 1.0).any() and (norms <= 1.0).any()
+    with pytest.raises(RuntimeError):
+        dec.decode(d["z"], d["entities"])
+    with pytest.raises(ValueError):
+        Stage1Decoder(p, num_head_latent=2, dim_head_latent=16, num_head_cross=4, dim_head_cross=16)
+    with pytest.raises(KeyError):
+        Stage1Decoder({k: v for k, v in p.items() if k != "post_quant.1.bias"}, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
