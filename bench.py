@@ -45,6 +45,10 @@ def flops_per_eval_per_traj(kw, T, L):
     return 6 * n * Cc * D + kw["depth"] * 4 * n * D * (4 * D + 2 * M + L + T)
 
 
+def done_updates(method, n_sample):
+    return n_sample if method == "ODE" else n_sample - 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,16 +224,33 @@ def main():
             if cal[c] > 20.0:
                 break
         th.set_num_threads(best)
+        n_sample = max(2, min(n_evals, int(round(15.0 * one / cal[best]))))  # about 15 s of CPU work
         tc = time.perf_counter()
-        run(n_sample)
+        cpu_final = run(n_sample)
         el = time.perf_counter() - tc
+        # parity of THIS workload in the same run: the same n_sample-update solve of trajectory 0 on the HIP path, both decoded to
+        # coordinates (HIP: lsl_decode; CPU: the oracle's decoder restatement) with a seeded frozen decoder of the MD17 shape
+        parity = None
+        if kw["in_dim"] == 32 and method == "ODE":  # (SDE runs draw their noise on different generators on the two sides)
+            from lam_slide_amd import Stage1Decoder
+            from lam_slide_amd.synthetic import seeded_decoder_state_dict
+            skw_n = dict(skw, num_steps=n_sample + 1)
+            mk1 = {k: v[:1] for k, v in mk.items()}
+            hip_final = Sampler(tr, fused=True, seed=1234).get_sample_fn(method, skw_n)(init[:1], net.forward, **mk1)[-1]
+            dsd = seeded_decoder_state_dict(seed=7)
+            dec = Stage1Decoder(dsd, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+            ent = th.arange(21)[None].expand(T, 21)
+            pos_hip = dec.decode(hip_final[0], ent.to(dev)).cpu()
+            pos_cpu = harness.decode(dsd, harness.DecoderShape(), cpu_final[0], ent)
+            parity = {"latents_rel_l2": harness.rel_l2(hip_final.cpu(), cpu_final), "decoded_coord_rel_l2": harness.rel_l2(pos_hip, pos_cpu),
+                      "what": f"trajectory 0, {done_updates(method, n_sample)} state updates, HIP sampler + HIP decode vs CPU oracle sampler + oracle decode"}
         done = n_sample if method == "ODE" else n_sample - 1
         per_update = el / done
         cpu = {"value": 1.0 / (per_update * n_evals), "unit": "trajectories/s", "cores": best, "kind": "port",
                "host_cores": host_cores, "calibration_s_per_update": {str(k): round(v, 2) for k, v in cal.items()},
                "sample": f"oracle restatement (pure PyTorch fp32, reference op structure, {'1' if method == 'ODE' else '2'} network "
                          f"evaluation(s) per update), B=1, {done} of {n_evals} state updates timed ({el:.1f} s) with {best} threads, "
-                         f"extrapolated linearly to {n_evals}"}
+                         f"extrapolated linearly to {n_evals}", "parity": parity}
 
     out = {
         "metric": "sampled trajectories/sec (50-step ODE) + decoded-coord L2 vs ref, MD17" if args.workload == "md17_bench"
