@@ -12,8 +12,8 @@ The compute lives in liblamslide_hip.so (include/lsl_api.h); build it with ``__g
 from . import _lib
 from .decoder import Stage1Decoder
 from .latent_si import LatentSIV3
-from .sampling import SecondStageSampler, min_ade_fde, sample_sharded, setup_conditioning, shard_bounds
+from .sampling import SecondStageSampler, min_ade_fde, sample_rollout, sample_sharded, setup_conditioning, shard_bounds
 from .transport import CreateTransport, ModelType, PathType, Sampler, SampleResult, Transport, WeightType
 
 __all__ = ["LatentSIV3", "CreateTransport", "Transport", "Sampler", "SampleResult", "ModelType", "PathType", "WeightType",
-           "SecondStageSampler", "setup_conditioning", "sample_sharded", "shard_bounds", "min_ade_fde", "Stage1Decoder", "_lib"]
+           "SecondStageSampler", "setup_conditioning", "sample_sharded", "shard_bounds", "min_ade_fde", "sample_rollout", "Stage1Decoder", "_lib"]

@@ -154,3 +154,23 @@ def min_ade_fde(trajectories: Tensor, target: Tensor) -> Tuple[Tensor, Tensor]:
     Returns (ADE, FDE), each [N]: the minimum over K of the time-averaged / final-frame L2 error."""
     err = torch.norm(trajectories - target[:, None], dim=-1)  # [N, K, T]
     return err.mean(dim=-1).min(dim=1).values, err[..., -1].min(dim=1).values
+
+
+@torch.no_grad()
+def sample_rollout(sample_positions: Callable[[Tensor], Tensor], cond_pos: Tensor, num_rollouts: int = 1, shift: float = 0.0,
+                   scale: float = 1.0) -> Tensor:
+    """Chained rollouts of one system (modules/sampling.py:44-63, ``SIAtom14SamplingWrapper.sample_rollout``): each rollout is
+    conditioned on the last frame of the previous one; everything stays on the device of ``cond_pos`` (no host round trips
+    between rollouts).  ``sample_positions(pos [R, A, D]) -> [T, R, A, D]`` is one conditioned sample (encode -> sampler -> decode,
+    e.g. ``SecondStageSampler.sample`` on the batch built from ``pos``).  Rollouts of ONE system are sequential by construction;
+    shard over systems, not over rollouts."""
+    cond = (cond_pos - shift) / scale
+    pos = cond.clone()
+    rollouts = []
+    for _ in range(num_rollouts):
+        pred = sample_positions(pos)
+        rollouts.append(pred)
+        pos = pred[-1].clone()
+    positions = torch.cat(rollouts)
+    positions[0] = cond
+    return positions * scale + shift

@@ -258,3 +258,22 @@ def test_stage1_decoder_packing_on_cpu(golden):
         Stage1Decoder(p, num_head_latent=2, dim_head_latent=16, num_head_cross=4, dim_head_cross=16)
     with pytest.raises(KeyError):
         Stage1Decoder({k: v for k, v in p.items() if k != "post_quant.1.bias"}, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+
+
+def test_sample_rollout_chains_on_last_frame():
+    """modules/sampling.py:44-63: rollout r is conditioned on the last frame of rollout r-1, frame 0 of the result is the
+    conditioning frame, shift / scale are removed before and restored after."""
+    from lam_slide_amd import sample_rollout
+    seen = []
+
+    def sample_positions(pos):
+        seen.append(pos.clone())
+        return torch.stack([pos + (t + 1) for t in range(3)])  # T = 3 frames drifting away from the conditioning frame
+
+    cond = torch.arange(8, dtype=torch.float32).reshape(2, 2, 2) * 2.0 + 10.0
+    out = sample_rollout(sample_positions, cond, num_rollouts=3, shift=10.0, scale=2.0)
+    norm = (cond - 10.0) / 2.0
+    assert out.shape == (9, 2, 2, 2) and len(seen) == 3
+    assert torch.equal(seen[0], norm) and torch.equal(seen[1], norm + 3) and torch.equal(seen[2], norm + 6)
+    assert torch.equal(out[0], cond)                                # frame 0 = the conditioning frame
+    assert torch.equal(out[4], (norm + 3 + 2) * 2.0 + 10.0)        # rollout 1, frame 1
