@@ -194,6 +194,36 @@ size_t lsl_decode_workspace_bytes(const lsl_decoder *d, int32_t frames, int32_t 
 int lsl_decode(lsl_decoder *d, const float *z, const int64_t *entities, int32_t frames, int32_t L, int32_t A, float *out,
                void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Frozen stage-1 encode, the step before setup_conditioning: stands in for
+ *   quant(Encoder(x, entities, mask))      (models/components/encoder.py:34-41,96-103; lightning_base.py:22-25,37-40)
+ * where x is the output of the dataset-specific prepare_inputs (first_stage/<dataset>.py), which stays the caller's. */
+typedef struct lsl_encoder_desc {    /* Encoder.__init__ arguments (encoder.py:46-61)                       */
+    int32_t dim_input, dim_emb, n_entities, dim_latent, num_latents;
+    int32_t heads_cross, dim_head_cross, heads_latent, dim_head_latent;
+    int32_t num_block_cross, num_block_attn;
+    int32_t act;                     /* 1 = erf GELU, 2 = tanh GELU                                       */
+} lsl_encoder_desc;
+
+typedef struct lsl_encoder_weights {
+    const float *table;              /* encoder.entity_embedding.embedding.weight, rows already clipped to max_norm */
+    const float *mlp_w1, *mlp_b1;    /* encoder.mlp.0 [dim_latent, dim_input + dim_emb]                    */
+    const float *mlp_w2, *mlp_b2;    /* encoder.mlp.2 [dim_input + dim_emb, dim_latent]                    */
+    const float *latents;            /* encoder.latents [num_latents, dim_latent]                          */
+    const lsl_dec_block *cross_blocks;  /* HOST array [num_block_cross] encoder.cross_attn_blocks.i (latents attend to the context) */
+    const lsl_dec_block *self_blocks;   /* HOST array [num_block_attn]  encoder.blocks_attn.i            */
+    const float *quant_w, *quant_b;  /* quant.0 [dim_latent, dim_latent]; quant.1 = LayerNorm without affine */
+} lsl_encoder_weights;
+
+typedef struct lsl_encoder lsl_encoder;
+int lsl_encoder_create(const lsl_encoder_desc *desc, const lsl_encoder_weights *w, lsl_encoder **out);
+void lsl_encoder_destroy(lsl_encoder *e);
+size_t lsl_encode_workspace_bytes(const lsl_encoder *e, int32_t frames, int32_t A);
+/* x: device [frames, A, dim_input]; entities: device [frames, A] int64; mask: device [frames, A] bytes, non-zero = real entity,
+ * or NULL (all real); out: device [frames, num_latents, dim_latent]. */
+int lsl_encode(lsl_encoder *e, const float *x, const int64_t *entities, const unsigned char *mask, int32_t frames, int32_t A, float *out,
+               void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,13 +7,15 @@ Public surface (mirrors the reference's for this path only):
   SecondStageSampler, setup_conditioning, sample_sharded
                                    <- SecondStageCondLightningBase.{sample, setup_conditioning} + batch sharding
   Stage1Decoder                    <- first_stage.decode = Decoder(post_quant(latents), entities) (frozen, after the sampler)
+  Stage1Encoder                    <- quant(Encoder(prepare_inputs(batch), entities, mask)) (frozen, before the sampler)
 The compute lives in liblamslide_hip.so (include/lsl_api.h); build it with ``__graft_entry__.build()``.
 """
 from . import _lib
 from .decoder import Stage1Decoder
+from .encoder import Stage1Encoder
 from .latent_si import LatentSIV3
 from .sampling import SecondStageSampler, min_ade_fde, sample_rollout, sample_sharded, setup_conditioning, shard_bounds
 from .transport import CreateTransport, ModelType, PathType, Sampler, SampleResult, Transport, WeightType
 
 __all__ = ["LatentSIV3", "CreateTransport", "Transport", "Sampler", "SampleResult", "ModelType", "PathType", "WeightType",
-           "SecondStageSampler", "setup_conditioning", "sample_sharded", "shard_bounds", "min_ade_fde", "sample_rollout", "Stage1Decoder", "_lib"]
+           "SecondStageSampler", "setup_conditioning", "sample_sharded", "shard_bounds", "min_ade_fde", "sample_rollout", "Stage1Decoder", "Stage1Encoder", "_lib"]

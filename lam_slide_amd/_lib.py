@@ -22,6 +22,7 @@ EXPORTED = (
     "lsl_model_set_chunk", "lsl_pass_size", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_debug_block", "lsl_debug_mods",
     "lsl_profile_enable", "lsl_profile_read",
     "lsl_decoder_create", "lsl_decoder_destroy", "lsl_decode_workspace_bytes", "lsl_decode",
+    "lsl_encoder_create", "lsl_encoder_destroy", "lsl_encode_workspace_bytes", "lsl_encode",
 )
 
 
@@ -59,6 +60,17 @@ class DecoderWeights(C.Structure):  # lsl_decoder_weights
     _fields_ = [("pq_w", C.c_void_p), ("pq_b", C.c_void_p), ("table", C.c_void_p), ("qm_w", C.c_void_p), ("qm_b", C.c_void_p),
                 ("self_blocks", C.POINTER(DecBlock)), ("cross_blocks", C.POINTER(DecBlock)), ("out_block", DecBlock),
                 ("head_w1", C.c_void_p), ("head_b1", C.c_void_p), ("head_w2", C.c_void_p), ("head_b2", C.c_void_p)]
+
+
+class EncoderDesc(C.Structure):  # lsl_encoder_desc
+    _fields_ = [(n, C.c_int32) for n in ("dim_input", "dim_emb", "n_entities", "dim_latent", "num_latents", "heads_cross", "dim_head_cross",
+                                         "heads_latent", "dim_head_latent", "num_block_cross", "num_block_attn", "act")]
+
+
+class EncoderWeights(C.Structure):  # lsl_encoder_weights
+    _fields_ = [("table", C.c_void_p), ("mlp_w1", C.c_void_p), ("mlp_b1", C.c_void_p), ("mlp_w2", C.c_void_p), ("mlp_b2", C.c_void_p),
+                ("latents", C.c_void_p), ("cross_blocks", C.POINTER(DecBlock)), ("self_blocks", C.POINTER(DecBlock)),
+                ("quant_w", C.c_void_p), ("quant_b", C.c_void_p)]
 
 
 class Step(C.Structure):
@@ -119,6 +131,13 @@ def load() -> C.CDLL:
     lib.lsl_decode_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.lsl_decode_workspace_bytes.restype = C.c_size_t
     lib.lsl_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                               C.c_void_p]
+    lib.lsl_encoder_create.argtypes = [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.POINTER(C.c_void_p)]
+    lib.lsl_encoder_destroy.argtypes = [C.c_void_p]
+    lib.lsl_encoder_destroy.restype = None
+    lib.lsl_encode_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.lsl_encode_workspace_bytes.restype = C.c_size_t
+    lib.lsl_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.c_void_p]
     if lib.lsl_version() != 1:
         raise RuntimeError("liblamslide_hip.so version mismatch")

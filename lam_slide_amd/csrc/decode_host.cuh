@@ -1,6 +1,12 @@
-// Host side of lsl_decode: the launch sequence of the frozen stage-1 decode (kernels in k_decode.cuh).
+// Host side of lsl_decode / lsl_encode: the launch sequences of the frozen stage-1 decode and encode (kernels in k_decode.cuh).
 #pragma once
 #include "k_decode.cuh"
+
+struct lsl_encoder {
+    lsl_encoder_desc d;
+    lsl_encoder_weights w;
+    std::vector<lsl_dec_block> cross_blocks, self_blocks;
+};
 
 struct lsl_decoder {
     lsl_decoder_desc d;
@@ -54,7 +60,7 @@ void dec_dense(int act, float *out, const float *in, const float *W, const float
 }
 
 int dec_attn(const DecAttnArgs &a, int frames, hipStream_t st) {
-    const size_t lds = (size_t)2 * a.Sk * (a.dh <= 16 ? 16 : a.dh <= 32 ? 32 : 64) * sizeof(float);
+    const size_t lds = ((size_t)2 * a.Sk * (a.dh <= 16 ? 16 : a.dh <= 32 ? 32 : 64) + a.Sk) * sizeof(float);
     if (a.dh > 64 || lds > 64 * 1024) return fail(-3, "decode attention: dim_head %d / %d keys exceed the LDS tile", a.dh, a.Sk);
     const dim3 grid(frames * a.H);
     if (a.dh <= 16) hipLaunchKernelGGL((k_dec_attn<16>), grid, dim3(256), lds, st, a);
@@ -66,12 +72,13 @@ int dec_attn(const DecAttnArgs &a, int frames, hipStream_t st) {
 // x <- x + to_out(attention(LN(x), LN_c(ctx)));  x <- x + FF(LN(x))     (torch_modules.py:221-264)
 // x: [frames * Sx, dim]; ctx: [frames * Sc, cdim] or nullptr (self-attention)
 int dec_block(const lsl_dec_block &b, float *x, int Sx, int dim, const float *ctx, int Sc, int cdim, int H, int dh, int act, int frames,
-              const DecWs &ws, hipStream_t st) {
+              const DecWs &ws, hipStream_t st, const unsigned char *key_mask = nullptr) {
     const int inner = H * dh, nx = frames * Sx;
     dec_ln(ws.xn, x, b.ln_w, b.ln_b, nx, dim, st);
     DecAttnArgs a{};
     a.q_scale = b.q_scale;
     a.k_scale = b.k_scale;
+    a.key_mask = key_mask;
     a.dh = dh;
     a.H = H;
     a.Sq = Sx;
@@ -102,6 +109,33 @@ int dec_block(const lsl_dec_block &b, float *x, int Sx, int dim, const float *ct
     dec_dense(act, ws.hid, ws.xn, b.ff_w1, b.ff_b1, nullptr, nx, dim, dim, st);
     dec_dense(0, x, ws.hid, b.ff_w2, b.ff_b2, x, nx, dim, dim, st);
     return 0;
+}
+
+// encoder scratch: the same buffers as the decoder's, sized for latents [frames*N, dim_latent] and context [frames*A, dim_ctx]
+size_t enc_carve(const lsl_encoder_desc &d, int frames, int A, char *base, DecWs *ws, float **ctx) {
+    const size_t nl = (size_t)frames * d.num_latents, na = (size_t)frames * A, nmax = std::max(nl, na);
+    const int dim_ctx = d.dim_input + d.dim_emb;
+    const int inner_l = d.heads_latent * d.dim_head_latent, inner_c = d.heads_cross * d.dim_head_cross;
+    const int dmax = std::max(dim_ctx, d.dim_latent), imax = std::max(3 * inner_l, 2 * inner_c);
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float *p = base ? reinterpret_cast<float *>(base + off) : nullptr;
+        off += dec_align(floats * sizeof(float));
+        return p;
+    };
+    DecWs w;
+    w.lat = take(nl * d.dim_latent);
+    w.q = nullptr;
+    float *c = take(na * dim_ctx);
+    w.xn = take(nmax * dmax);
+    w.cn = take(nmax * dmax);
+    w.qb = take(nmax * imax);
+    w.kvb = take(nmax * imax);
+    w.att = take(nmax * std::max(inner_l, inner_c));
+    w.hid = take(nmax * dmax);
+    if (ws) *ws = w;
+    if (ctx) *ctx = c;
+    return off;
 }
 
 }  // namespace

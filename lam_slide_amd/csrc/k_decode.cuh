@@ -1,4 +1,5 @@
-// fp32 kernels of the frozen stage-1 decode that follows the sampler: post_quant -> Decoder
+// fp32 kernels of the frozen stage-1 decode that follows the sampler and of the encode that precedes it (8f.3:
+// models/components/encoder.py:34-41,96-103 + quant, lightning_base.py:22-25,37-40): post_quant -> Decoder
 // (models/composites/lightning_base.py:28-31,42-44, models/components/decoder.py:82-102, modules/torch_modules.py:104-264).
 // The decode is < 0.1 % of the path's FLOPs (a few hundred MFLOP per frame against 13 TFLOP per trajectory), so these are
 // plain fp32 kernels: no bf16 rounding enters the decoded coordinates, the quantity the parity metric is stated on.
@@ -34,6 +35,24 @@ __global__ void __launch_bounds__(256) k_dec_gather(float *out, const float *tab
     long e = idx[row];
     e = e < 0 ? 0 : (e >= n_entities ? n_entities - 1 : e);
     for (int i = lane; i < E; i += 64) out[(size_t)row * E + i] = table[(size_t)e * E + i];
+}
+
+// encoder context rows: out[r] = [x[r] | table[entities[r]]]   (encoder.py:34-37)
+__global__ void __launch_bounds__(256) k_enc_context(float *out, const float *x, const float *table, const int64_t *idx, int rows, int DX,
+                                                     int E, int n_entities) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    long e = idx[row];
+    e = e < 0 ? 0 : (e >= n_entities ? n_entities - 1 : e);
+    float *o = out + (size_t)row * (DX + E);
+    for (int i = lane; i < DX; i += 64) o[i] = x[(size_t)row * DX + i];
+    for (int i = lane; i < E; i += 64) o[DX + i] = table[(size_t)e * E + i];
+}
+
+// the learned latent array repeated for every frame (encoder.py:39: repeat "N D -> B N D")
+__global__ void __launch_bounds__(256) k_enc_broadcast(float *out, const float *latents, long total, int per_frame) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = latents[i % per_frame];
 }
 
 template <int ACT>
@@ -100,15 +119,16 @@ struct DecAttnArgs {
     const float *q, *k, *v;  // row strides ldq, ldk, ldv; head h at column offset h * dh
     float *out;              // row stride ldo
     const float *q_scale, *k_scale;  // [dh] or nullptr (no QK norm)
+    const unsigned char *key_mask;   // [frames, Sk], non-zero = attend (attn_mask of F.scaled_dot_product_attention), or nullptr
     int ldq, ldk, ldv, ldo;
     int Sq, Sk, dh, H;
 };
 
 template <int DH>
 __global__ void __launch_bounds__(256) k_dec_attn(DecAttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float kv[];  // K [Sk][DH] then V [Sk][DH]
+    extern __shared__ __attribute__((aligned(16))) float kv[];  // K [Sk][DH], V [Sk][DH], additive key mask [Sk] (0 or -inf)
     const int f = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    float *Ks = kv, *Vs = kv + (size_t)a.Sk * DH;
+    float *Ks = kv, *Vs = kv + (size_t)a.Sk * DH, *Ms = kv + (size_t)2 * a.Sk * DH;
     const int dh = a.dh;
     for (int s = threadIdx.x; s < a.Sk; s += blockDim.x) {
         const float *kr = a.k + (size_t)(f * a.Sk + s) * a.ldk + h * dh;
@@ -120,6 +140,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(DecAttnArgs a) {
             Ks[s * DH + d] = a.k_scale ? kr[d] * rr * a.k_scale[d] : kr[d];
             Vs[s * DH + d] = vr[d];
         }
+        Ms[s] = (a.key_mask && !a.key_mask[(size_t)f * a.Sk + s]) ? -INFINITY : 0.0f;
     }
     __syncthreads();
     const float scale = rsqrtf((float)dh);
@@ -142,7 +163,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(DecAttnArgs a) {
 #pragma unroll
             for (int d = 0; d < DH; ++d)
                 if (d < dh) sc = fmaf(q[d], Ks[s * DH + d], sc);
-            m = fmaxf(m, sc);
+            m = fmaxf(m, sc + Ms[s]);
         }
         float o[DH], l = 0.0f;
 #pragma unroll
@@ -152,7 +173,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(DecAttnArgs a) {
 #pragma unroll
             for (int d = 0; d < DH; ++d)
                 if (d < dh) sc = fmaf(q[d], Ks[s * DH + d], sc);
-            const float p = __expf(sc - m);
+            const float p = __expf(sc + Ms[s] - m);
             l += p;
 #pragma unroll
             for (int d = 0; d < DH; ++d)

@@ -691,4 +691,60 @@ int lsl_decode(lsl_decoder *dec, const float *z, const int64_t *entities, int32_
     return 0;
 }
 
+int lsl_encoder_create(const lsl_encoder_desc *desc, const lsl_encoder_weights *w, lsl_encoder **out) {
+    if (!desc || !w || !out) return fail(-1, "null encoder argument");
+    const lsl_encoder_desc &d = *desc;
+    if (d.dim_input % 4 || d.dim_emb % 4 || d.dim_latent % 4 || (d.heads_latent * d.dim_head_latent) % 4 || (d.heads_cross * d.dim_head_cross) % 4)
+        return fail(-3, "encoder widths must be multiples of 4");
+    if (d.dim_head_latent > 64 || d.dim_head_cross > 64 || d.dim_head_latent < 1 || d.dim_head_cross < 1) return fail(-3, "encoder dim_head must be 1..64");
+    if (d.act != 1 && d.act != 2) return fail(-3, "encoder activation must be 1 (erf GELU) or 2 (tanh GELU)");
+    if (d.num_block_attn < 0 || d.num_block_cross < 0 || d.num_latents < 1 || d.n_entities < 1) return fail(-3, "bad encoder description");
+    lsl_encoder *enc = new lsl_encoder();
+    enc->d = d;
+    enc->w = *w;
+    if (d.num_block_cross) enc->cross_blocks.assign(w->cross_blocks, w->cross_blocks + d.num_block_cross);
+    if (d.num_block_attn) enc->self_blocks.assign(w->self_blocks, w->self_blocks + d.num_block_attn);
+    enc->w.cross_blocks = enc->cross_blocks.data();
+    enc->w.self_blocks = enc->self_blocks.data();
+    *out = enc;
+    return 0;
+}
+
+void lsl_encoder_destroy(lsl_encoder *e) { delete e; }
+
+size_t lsl_encode_workspace_bytes(const lsl_encoder *e, int32_t frames, int32_t A) {
+    if (!e || frames <= 0 || A <= 0) return 0;
+    return enc_carve(e->d, frames, A, nullptr, nullptr, nullptr);
+}
+
+// quant(Encoder.forward(x, entities, mask))   (encoder.py:96-103, lightning_base.py:37-40)
+int lsl_encode(lsl_encoder *enc, const float *x, const int64_t *entities, const unsigned char *mask, int32_t frames, int32_t A, float *out,
+               void *workspace, size_t workspace_bytes, void *stream) {
+    if (!enc || !x || !entities || !out) return fail(-1, "null encode argument");
+    if (frames <= 0 || A <= 0) return fail(-3, "encode: empty input");
+    const lsl_encoder_desc &d = enc->d;
+    const lsl_encoder_weights &w = enc->w;
+    if (workspace_bytes < enc_carve(d, frames, A, nullptr, nullptr, nullptr) || !workspace) return fail(-4, "encode workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    DecWs ws;
+    float *ctx;
+    enc_carve(d, frames, A, (char *)workspace, &ws, &ctx);
+    const int N = d.num_latents, nl = frames * N, na = frames * A, dim_ctx = d.dim_input + d.dim_emb;
+    // prepare_inputs of EncoderBase: context = mlp(cat(x, entity_embedding(entities))), latents = the learned array per frame
+    hipLaunchKernelGGL(k_enc_context, dim3((na + 3) / 4), dim3(256), 0, st, ws.xn, x, w.table, entities, na, d.dim_input, d.dim_emb, d.n_entities);
+    dec_dense(d.act, ws.hid, ws.xn, w.mlp_w1, w.mlp_b1, nullptr, na, dim_ctx, d.dim_latent, st);
+    dec_dense(0, ctx, ws.hid, w.mlp_w2, w.mlp_b2, nullptr, na, d.dim_latent, dim_ctx, st);
+    const long total = (long)nl * d.dim_latent;
+    hipLaunchKernelGGL(k_enc_broadcast, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws.lat, w.latents, total, N * d.dim_latent);
+    for (int i = 0; i < d.num_block_cross; ++i)
+        if (int rc = dec_block(w.cross_blocks[i], ws.lat, N, d.dim_latent, ctx, A, dim_ctx, d.heads_cross, d.dim_head_cross, d.act, frames, ws, st, mask)) return rc;
+    for (int i = 0; i < d.num_block_attn; ++i)
+        if (int rc = dec_block(w.self_blocks[i], ws.lat, N, d.dim_latent, nullptr, 0, 0, d.heads_latent, d.dim_head_latent, d.act, frames, ws, st)) return rc;
+    // quant: Linear(dim_latent, dim_latent) then LayerNorm(dim_latent, elementwise_affine=False)
+    dec_dense(0, ws.hid, ws.lat, w.quant_w, w.quant_b, nullptr, nl, d.dim_latent, d.dim_latent, st);
+    dec_ln(out, ws.hid, nullptr, nullptr, nl, d.dim_latent, st);
+    LSL_CHECK_LAUNCH("lsl_encode");
+    return 0;
+}
+
 }  // extern "C"

@@ -94,7 +94,7 @@ def _heads(t, h):
     return t.reshape(b, n, h, hd // h).permute(0, 2, 1, 3)
 
 
-def _mha(p, pre, xq, ctx, heads, dim_head, qk_norm, fused_qkv):
+def _mha(p, pre, xq, ctx, heads, dim_head, qk_norm, fused_qkv, mask=None):
     if fused_qkv:
         q, k, v = torch.nn.functional.linear(xq, p[pre + ".to_qkv.weight"]).chunk(3, dim=-1)
     else:
@@ -105,6 +105,8 @@ def _mha(p, pre, xq, ctx, heads, dim_head, qk_norm, fused_qkv):
         q = _rms(q, p[pre + ".norm.query_norm.scale"]).to(v.dtype)
         k = _rms(k, p[pre + ".norm.key_norm.scale"]).to(v.dtype)
     s = torch.matmul(q, k.transpose(-1, -2)) * dim_head ** -0.5
+    if mask is not None:  # bool [b, keys], True = attend (torch_modules.py:196-199: attn_mask of F.scaled_dot_product_attention)
+        s = s.masked_fill(~mask[:, None, None, :].bool(), float("-inf"))
     o = torch.matmul(torch.softmax(s, dim=-1), v)
     o = o.permute(0, 2, 1, 3).reshape(xq.shape[0], xq.shape[1], heads * dim_head)
     return torch.nn.functional.linear(o, p[pre + ".to_out.weight"], p[pre + ".to_out.bias"])
@@ -116,16 +118,16 @@ def _ff(p, pre, x, act):
     return torch.nn.functional.linear(x, p[pre + ".fn.net.1.weight"], p[pre + ".fn.net.1.bias"])
 
 
-def _self_block(p, pre, x, ds: DecoderShape):
+def _self_block(p, pre, x, ds):
     xn = _ln(x, p[pre + ".attn.norm.weight"], p[pre + ".attn.norm.bias"])
     x = _mha(p, pre + ".attn.fn", xn, xn, ds.num_head_latent, ds.dim_head_latent, ds.qk_norm, True) + x
     return _ff(p, pre + ".ff", x, ds.act) + x
 
 
-def _cross_block(p, pre, x, ctx, heads, dim_head, ds: DecoderShape):
+def _cross_block(p, pre, x, ctx, heads, dim_head, ds, mask=None):
     xn = _ln(x, p[pre + ".attn.norm.weight"], p[pre + ".attn.norm.bias"])
     cn = _ln(ctx, p[pre + ".attn.norm_context.weight"], p[pre + ".attn.norm_context.bias"])
-    x = _mha(p, pre + ".attn.fn", xn, cn, heads, dim_head, ds.qk_norm, False) + x
+    x = _mha(p, pre + ".attn.fn", xn, cn, heads, dim_head, ds.qk_norm, False, mask) + x
     return _ff(p, pre + ".ff", x, ds.act) + x
 
 
@@ -159,3 +161,43 @@ def compute_errors(selected_traj: Tensor, all_target: Tensor) -> Tuple[Tensor, T
     error_ave = error.mean(dim=-1)
     error_final = error[..., -1]
     return error_ave.min(dim=1).values, error_final.min(dim=1).values
+
+
+# ----------------------------------------------------------------------------------------------------------
+# frozen stage-1 encoder (the step before the path)
+
+
+@dataclass(frozen=True)
+class EncoderShape:
+    dim_input: int = 128
+    dim_latent: int = 32
+    num_latents: int = 192
+    dim_head_cross: int = 16
+    dim_head_latent: int = 16
+    num_head_cross: int = 8
+    num_head_latent: int = 2
+    num_block_cross: int = 1
+    num_block_attn: int = 1
+    qk_norm: bool = True
+    act: str = "gelu_erf"
+
+
+def encode(p: Dict[str, Tensor], es: EncoderShape, x: Tensor, entities: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    """x: [F, A, dim_input] per-entity inputs (the dataset-specific ``prepare_inputs`` output, first_stage/md17.py:52-58);
+    entities [F, A] int; mask [F, A] bool (True = real entity) -> latents [F, num_latents, dim_latent].
+
+    models/components/encoder.py:34-41,96-103 (context = mlp(cat(x, entity_embedding)); learned latents cross-attend to the
+    context under the entity mask, then self-attend) followed by ``quant`` = Linear + LayerNorm without affine
+    (lightning_base.py:22-25,37-40).  Parameter names: ``encoder.*`` and ``quant.0.*``."""
+    table = p["encoder.entity_embedding.embedding.weight"]
+    norms = table.norm(dim=-1, keepdim=True)
+    table = torch.where(norms > 1.0, table / (norms + 1e-7), table)
+    ctx = torch.cat([x, table[entities]], dim=-1)
+    ctx = torch.nn.functional.linear(_act(torch.nn.functional.linear(ctx, p["encoder.mlp.0.weight"], p["encoder.mlp.0.bias"]), es.act),
+                                     p["encoder.mlp.2.weight"], p["encoder.mlp.2.bias"])
+    lat = p["encoder.latents"][None].expand(x.shape[0], -1, -1)
+    for i in range(es.num_block_cross):
+        lat = _cross_block(p, f"encoder.cross_attn_blocks.{i}", lat, ctx, es.num_head_cross, es.dim_head_cross, es, mask)
+    for i in range(es.num_block_attn):
+        lat = _self_block(p, f"encoder.blocks_attn.{i}", lat, es)
+    return _ln(torch.nn.functional.linear(lat, p["quant.0.weight"], p["quant.0.bias"]))

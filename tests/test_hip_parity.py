@@ -368,3 +368,22 @@ def test_sample_then_decode_on_device(golden, dev):
     err = rel_l2(pos, want)
     print(f"sample + decode on device: decoded coordinates rel L2 {err:.3e}")
     assert err < 1e-3
+
+
+def test_stage1_encode_against_reference_latents(golden, dev):
+    """Encoder + quant on the HIP path against latents produced by the reference's own Encoder module with a ragged
+    entity mask (tests/golden/f7_encode.npz)."""
+    from lam_slide_amd import Stage1Encoder
+    d = golden("f7_encode.npz")
+    enc = Stage1Encoder(d.group("p"), num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16, act="gelu_erf")
+    z = enc.encode(d["x"].to(dev), d["entities"].to(dev), d["mask"].to(dev)).cpu()
+    err = rel_l2(z, d["z"])
+    print(f"stage-1 encode rel L2 {err:.3e}")
+    assert err < 1e-5
+    part = enc.encode(d["x"][1:2].to(dev), d["entities"][1:2].to(dev), d["mask"][1:2].to(dev)).cpu()
+    assert torch.equal(part, z[1:2])
+    # masked-out entities do not influence the latents
+    x2 = d["x"].clone()
+    x2[1, 15:] = 1e3
+    z2 = enc.encode(x2.to(dev), d["entities"].to(dev), d["mask"].to(dev)).cpu()
+    assert torch.equal(z2[1], z[1])

@@ -122,3 +122,11 @@ def test_f6_decode(golden):
     f = golden("f6_decode.npz")
     pos = harness.decode(f.group("p"), harness.DecoderShape(), f["z"], f["entities"])
     assert rel_l2(pos, f["pos"]) < 2e-6
+
+
+def test_f7_encoder_restatement_matches_reference_module(golden):
+    """oracle.harness.encode against latents produced by the reference's Encoder + quant (ragged entity mask)."""
+    from oracle import harness
+    d = golden("f7_encode.npz")
+    z = harness.encode(d.group("p"), harness.EncoderShape(num_latents=48), d["x"], d["entities"], d["mask"])
+    assert rel_l2(z, d["z"]) < 2e-6

@@ -14,6 +14,7 @@ Fixture families:
   f4_cfg1.npz       true cfg-1 shape (B=1, 10 Euler updates), weights from oracle.random_params(seed)
   f5_cond.npz       setup_conditioning, executed from the reference source via ast extraction
   f6_decode.npz     frozen stage-1 decode of latents -> positions (MD17 decoder shape, seeded weights)
+  f7_encode.npz     frozen stage-1 Encoder + quant with a ragged entity mask (MD17 encoder shape, 48 latents)
 """
 import ast
 import os
@@ -381,7 +382,36 @@ def f6():
     npz("f6_decode.npz", p=p, z=z, entities=ent, pos=pos)
 
 
+# ------------------------------------------------------------------------------------------- F7
+def f7():
+    from functools import partial
+    from src.models.components.encoder import Encoder
+    es = harness.EncoderShape(num_latents=48)
+    torch.manual_seed(9)
+    emb = EntityEmbeddingOrthogonal(n_entiy_embeddings=32, embedding_dim=128, max_norm=1)
+    enc = Encoder(dim_input=es.dim_input, dim_latent=es.dim_latent, dim_head_cross=16, dim_head_latent=16, num_latents=es.num_latents,
+                  num_head_cross=8, num_head_latent=2, num_block_cross=1, num_block_attn=1, qk_norm=True, entity_embedding=emb,
+                  act=partial(RefGELU)).eval()
+    quant = torch.nn.Sequential(torch.nn.Linear(32, 32), torch.nn.LayerNorm(32, elementwise_affine=False)).eval()
+    emb.embedding.weight.mul_(torch.linspace(0.5, 1.8, 32)[:, None])
+    p = {"quant.0.weight": quant[0].weight.clone(), "quant.0.bias": quant[0].bias.clone()}
+    p.update({"encoder." + k: v.clone() for k, v in enc.state_dict().items()})
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(5, 21, es.dim_input, generator=g)
+    ent = torch.stack([torch.randperm(32, generator=g)[:21] for _ in range(5)])
+    mask = torch.ones(5, 21, dtype=torch.bool)
+    mask[1, 15:] = False   # ragged systems: padded entities are masked out of the cross-attention
+    mask[3, 9:] = False
+    with torch.no_grad():
+        z = quant(enc(x=x, entities=ent, mask=mask))
+    mine = harness.encode(p, es, x, ent, mask)
+    e = rel(mine, z)
+    print(f"F7 encode: oracle rel {e:.2e}; params {sum(v.numel() for v in p.values())}")
+    assert e < 2e-6
+    npz("f7_encode.npz", p=p, x=x, entities=ent, mask=mask, z=z)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7"]
     for w in which:
         globals()[w]()
