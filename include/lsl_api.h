@@ -172,6 +172,8 @@ typedef struct lsl_decoder_desc {    /* Decoder.__init__ arguments (decoder.py:1
     int32_t num_block_attn, num_block_cross;
     int32_t act;                     /* 1 = erf GELU (src.modules.torch_modules.GELU), 2 = nn.GELU(approximate="tanh") */
     int32_t out_dim;                 /* width of the decoded output head (3 for "pos")                    */
+    int32_t num_split;               /* DecoderQuerySplitter (decoder.py:313-411, peptide): every latent becomes num_split context tokens
+                                        for the output block; 0 or 1 = plain Decoder                           */
 } lsl_decoder_desc;
 
 typedef struct lsl_decoder_weights {
@@ -182,6 +184,8 @@ typedef struct lsl_decoder_weights {
     const lsl_dec_block *self_blocks;   /* HOST array [num_block_attn]  decoder.self_attn_blocks.i       */
     const lsl_dec_block *cross_blocks;  /* HOST array [num_block_cross] decoder.cross_attn_blocks.i      */
     lsl_dec_block out_block;            /* decoder.output_block (queries attend to the latents)          */
+    const float *ext_w, *ext_b;      /* decoder.extender.1 (1x1 Conv1d) as [num_split * dim_latent, dim_latent] with rows reordered to
+                                        (split, feature): row n * dim_latent + d = conv channel d * num_split + n; NULL without split */
     const float *head_w1, *head_b1;  /* decoder.output_layers.<name>.0 [dim_query, dim_query]             */
     const float *head_w2, *head_b2;  /* decoder.output_layers.<name>.2 [out_dim, dim_query]               */
 } lsl_decoder_weights;

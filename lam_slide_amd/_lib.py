@@ -53,13 +53,13 @@ class DecBlock(C.Structure):  # lsl_dec_block
 
 class DecoderDesc(C.Structure):  # lsl_decoder_desc
     _fields_ = [(n, C.c_int32) for n in ("in_dim", "dim_latent", "dim_query", "dim_emb", "n_entities", "heads_latent", "dim_head_latent",
-                                         "heads_cross", "dim_head_cross", "num_block_attn", "num_block_cross", "act", "out_dim")]
+                                         "heads_cross", "dim_head_cross", "num_block_attn", "num_block_cross", "act", "out_dim", "num_split")]
 
 
 class DecoderWeights(C.Structure):  # lsl_decoder_weights
     _fields_ = [("pq_w", C.c_void_p), ("pq_b", C.c_void_p), ("table", C.c_void_p), ("qm_w", C.c_void_p), ("qm_b", C.c_void_p),
                 ("self_blocks", C.POINTER(DecBlock)), ("cross_blocks", C.POINTER(DecBlock)), ("out_block", DecBlock),
-                ("head_w1", C.c_void_p), ("head_b1", C.c_void_p), ("head_w2", C.c_void_p), ("head_b2", C.c_void_p)]
+                ("ext_w", C.c_void_p), ("ext_b", C.c_void_p), ("head_w1", C.c_void_p), ("head_b1", C.c_void_p), ("head_w2", C.c_void_p), ("head_b2", C.c_void_p)]
 
 
 class EncoderDesc(C.Structure):  # lsl_encoder_desc

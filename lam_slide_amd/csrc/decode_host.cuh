@@ -17,14 +17,15 @@ struct lsl_decoder {
 namespace {
 
 struct DecWs {
-    float *lat, *q, *xn, *cn, *qb, *kvb, *att, *hid;
+    float *lat, *q, *xn, *cn, *qb, *kvb, *att, *hid, *ext;
 };
 
 inline size_t dec_align(size_t n) { return (n + 63) & ~(size_t)63; }
 
 // every buffer in floats; returns the total in bytes
 size_t dec_carve(const lsl_decoder_desc &d, int frames, int L, int A, char *base, DecWs *ws) {
-    const size_t nl = (size_t)frames * L, na = (size_t)frames * A, nmax = std::max(nl, na);
+    const int split = d.num_split > 1 ? d.num_split : 1;
+    const size_t nl = (size_t)frames * L, na = (size_t)frames * A, nmax = std::max(nl * split, na);
     const int inner_l = d.heads_latent * d.dim_head_latent, inner_c = d.heads_cross * d.dim_head_cross;
     const int dmax = std::max(std::max(d.dim_latent, d.dim_query), std::max(d.in_dim, d.dim_emb));
     const int imax = std::max(3 * inner_l, 2 * inner_c);
@@ -43,6 +44,7 @@ size_t dec_carve(const lsl_decoder_desc &d, int frames, int L, int A, char *base
     w.kvb = take(nmax * imax);
     w.att = take(nmax * std::max(inner_l, inner_c));
     w.hid = take(nmax * dmax);
+    w.ext = split > 1 ? take(nl * split * d.dim_latent) : nullptr;
     if (ws) *ws = w;
     return off;
 }
@@ -133,6 +135,7 @@ size_t enc_carve(const lsl_encoder_desc &d, int frames, int A, char *base, DecWs
     w.kvb = take(nmax * imax);
     w.att = take(nmax * std::max(inner_l, inner_c));
     w.hid = take(nmax * dmax);
+    w.ext = nullptr;
     if (ws) *ws = w;
     if (ctx) *ctx = c;
     return off;

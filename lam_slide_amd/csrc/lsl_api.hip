@@ -643,7 +643,8 @@ int lsl_decoder_create(const lsl_decoder_desc *desc, const lsl_decoder_weights *
         return fail(-3, "decoder widths must be multiples of 4");
     if (d.dim_head_latent > 64 || d.dim_head_cross > 64 || d.dim_head_latent < 1 || d.dim_head_cross < 1) return fail(-3, "decoder dim_head must be 1..64");
     if (d.act != 1 && d.act != 2) return fail(-3, "decoder activation must be 1 (erf GELU) or 2 (tanh GELU)");
-    if (d.num_block_attn < 0 || d.num_block_cross < 0 || d.out_dim < 1 || d.n_entities < 1) return fail(-3, "bad decoder description");
+    if (d.num_block_attn < 0 || d.num_block_cross < 0 || d.out_dim < 1 || d.n_entities < 1 || d.num_split < 0) return fail(-3, "bad decoder description");
+    if (d.num_split > 1 && (!w->ext_w || !w->ext_b)) return fail(-2, "decoder with num_split > 1 needs the extender weights");
     lsl_decoder *dec = new lsl_decoder();
     dec->d = d;
     dec->w = *w;
@@ -684,7 +685,14 @@ int lsl_decode(lsl_decoder *dec, const float *z, const int64_t *entities, int32_
         if (int rc = dec_block(w.self_blocks[i], ws.lat, L, d.dim_latent, nullptr, 0, 0, d.heads_latent, d.dim_head_latent, d.act, frames, ws, st)) return rc;
     for (int i = 0; i < d.num_block_cross; ++i)
         if (int rc = dec_block(w.cross_blocks[i], ws.lat, L, d.dim_latent, ws.q, A, d.dim_query, d.heads_cross, d.dim_head_cross, d.act, frames, ws, st)) return rc;
-    if (int rc = dec_block(w.out_block, ws.q, A, d.dim_query, ws.lat, L, d.dim_latent, d.heads_cross, d.dim_head_cross, d.act, frames, ws, st)) return rc;
+    const float *ctx = ws.lat;
+    int Lc = L;
+    if (d.num_split > 1) {  // extender: 1x1 conv D -> D*N per latent, "B (D N) L -> B (L N) D"; the host reordered the rows to (N, D)
+        dec_dense(0, ws.ext, ws.lat, w.ext_w, w.ext_b, nullptr, nl, d.dim_latent, d.num_split * d.dim_latent, st);
+        ctx = ws.ext;
+        Lc = L * d.num_split;
+    }
+    if (int rc = dec_block(w.out_block, ws.q, A, d.dim_query, ctx, Lc, d.dim_latent, d.heads_cross, d.dim_head_cross, d.act, frames, ws, st)) return rc;
     dec_dense(d.act, ws.hid, ws.q, w.head_w1, w.head_b1, nullptr, na, d.dim_query, d.dim_query, st);
     dec_dense(0, out, ws.hid, w.head_w2, w.head_b2, nullptr, na, d.dim_query, d.out_dim, st);
     LSL_CHECK_LAUNCH("lsl_decode");

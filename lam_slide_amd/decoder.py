@@ -1,6 +1,7 @@
 """Frozen stage-1 decode on the MI355X: ``first_stage.decode(latents, entities)`` of the reference
 (models/composites/lightning_base.py:42-44 = ``Decoder(post_quant(latents), entities)``, models/components/decoder.py:12-102),
-the step right after the sampler.  Inference only, fp32, through ``lsl_decode`` of liblamslide_hip.so.
+the step right after the sampler.  Inference only, fp32, through ``lsl_decode`` of liblamslide_hip.so.  The peptide
+variant ``DecoderQuerySplitter`` (decoder.py:313-411) is recognised by its ``decoder.extender.1.*`` parameters.
 
 The weights are taken from the first-stage state dict under the reference's own names (``post_quant.1.*``, ``decoder.*``); the
 constructor arguments that cannot be read off the weight shapes carry the reference's names (decoder.py:14-29).
@@ -55,6 +56,15 @@ class Stage1Decoder:
             raise ValueError("num_head_latent * dim_head_latent does not match decoder.self_attn_blocks.0.attn.fn.to_qkv.weight")
         self.act, self.output, self.max_norm = act, output, max_norm
         self._sd = {k: v.detach().to(torch.float32) for k, v in sd.items() if k.startswith(("post_quant.", "decoder."))}
+        # DecoderQuerySplitter (decoder.py:384-388): Conv1d(D, D*N, 1) then "B (D N) L -> B (L N) D"; as a Linear whose rows are
+        # reordered from channel d*N + n to n*D + d, the output of one latent IS its N context tokens back to back
+        self.num_split = 0
+        if "decoder.extender.1.weight" in self._sd:
+            w, b = self._sd.pop("decoder.extender.1.weight")[..., 0], self._sd.pop("decoder.extender.1.bias")
+            n = w.shape[0] // self.dim_latent
+            self.num_split = int(n)
+            self._sd["decoder.extender.rows"] = w.reshape(self.dim_latent, n, self.dim_latent).permute(1, 0, 2).reshape(n * self.dim_latent, self.dim_latent).contiguous()
+            self._sd["decoder.extender.rows_bias"] = b.reshape(self.dim_latent, n).t().reshape(-1).contiguous()
         self._sd["decoder.entity_embedding.embedding.weight"] = renorm_table(self._sd["decoder.entity_embedding.embedding.weight"], max_norm)
         self._handle = C.c_void_p()
         self._dev_tensors: List[Tensor] = []
@@ -97,10 +107,11 @@ class Stage1Decoder:
             table=self._p("decoder.entity_embedding.embedding.weight", dev),
             qm_w=self._p("decoder.query_mlp.1.weight", dev), qm_b=self._p("decoder.query_mlp.1.bias", dev),
             self_blocks=selfs, cross_blocks=cross, out_block=self._block("decoder.output_block", dev, True),
+            ext_w=self._p("decoder.extender.rows", dev), ext_b=self._p("decoder.extender.rows_bias", dev),
             head_w1=self._p(f"decoder.output_layers.{self.output}.0.weight", dev), head_b1=self._p(f"decoder.output_layers.{self.output}.0.bias", dev),
             head_w2=self._p(f"decoder.output_layers.{self.output}.2.weight", dev), head_b2=self._p(f"decoder.output_layers.{self.output}.2.bias", dev))
         desc = _lib.DecoderDesc(self.in_dim, self.dim_latent, self.dim_query, self.dim_emb, self.n_entities, self.heads_latent, self.dim_head_latent,
-                                self.heads_cross, self.dim_head_cross, self.num_block_attn, self.num_block_cross, _ACT[self.act], self.out_dim)
+                                self.heads_cross, self.dim_head_cross, self.num_block_attn, self.num_block_cross, _ACT[self.act], self.out_dim, self.num_split)
         _lib.check(lib.lsl_decoder_create(C.byref(desc), C.byref(w), C.byref(self._handle)))
         self.device = dev
         return self

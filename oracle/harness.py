@@ -146,6 +146,11 @@ def decode(p: Dict[str, Tensor], ds: DecoderShape, z: Tensor, entities: Tensor) 
         lat = _self_block(p, f"decoder.self_attn_blocks.{i}", lat, ds)
     for i in range(ds.num_block_cross):
         lat = _cross_block(p, f"decoder.cross_attn_blocks.{i}", lat, q, ds.num_head_cross, ds.dim_head_cross, ds)
+    if "decoder.extender.1.weight" in p:  # DecoderQuerySplitter (decoder.py:384-388,407): 1x1 Conv1d D -> D*N, "B (D N) L -> B (L N) D"
+        w, b = p["decoder.extender.1.weight"][..., 0], p["decoder.extender.1.bias"]
+        n_split = w.shape[0] // lat.shape[-1]
+        y = torch.nn.functional.linear(lat, w, b)  # [F, L, D*N], channel = d * N + n
+        lat = y.reshape(y.shape[0], y.shape[1], lat.shape[-1], n_split).permute(0, 1, 3, 2).reshape(y.shape[0], y.shape[1] * n_split, lat.shape[-1])
     o = _cross_block(p, "decoder.output_block", q, lat, ds.num_head_cross, ds.dim_head_cross, ds)
     o = _act(torch.nn.functional.linear(o, p["decoder.output_layers.pos.0.weight"], p["decoder.output_layers.pos.0.bias"]), ds.act)
     return torch.nn.functional.linear(o, p["decoder.output_layers.pos.2.weight"], p["decoder.output_layers.pos.2.bias"])

@@ -387,3 +387,16 @@ def test_stage1_encode_against_reference_latents(golden, dev):
     x2[1, 15:] = 1e3
     z2 = enc.encode(x2.to(dev), d["entities"].to(dev), d["mask"].to(dev)).cpu()
     assert torch.equal(z2[1], z[1])
+
+
+def test_stage1_decode_query_splitter_cross_block_tanh(golden, dev):
+    """The peptide decoder variant (DecoderQuerySplitter: every latent expands to 4 context tokens through a 1x1 conv), with one
+    latent<-query cross-attention block and the tanh GELU, against the reference module's positions (f8_decode_split.npz)."""
+    from lam_slide_amd import Stage1Decoder
+    d = golden("f8_decode_split.npz")
+    dec = Stage1Decoder(d.group("p"), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16, act="gelu_tanh")
+    assert (dec.num_split, dec.num_block_cross) == (4, 1)
+    pos = dec.decode(d["z"].to(dev), d["entities"].to(dev)).cpu()
+    err = rel_l2(pos, d["pos"])
+    print(f"stage-1 decode (query splitter) rel L2 {err:.3e}")
+    assert err < 1e-5

@@ -130,3 +130,11 @@ def test_f7_encoder_restatement_matches_reference_module(golden):
     d = golden("f7_encode.npz")
     z = harness.encode(d.group("p"), harness.EncoderShape(num_latents=48), d["x"], d["entities"], d["mask"])
     assert rel_l2(z, d["z"]) < 2e-6
+
+
+def test_f8_decoder_query_splitter_restatement(golden):
+    """oracle.harness.decode (extender + cross block + tanh GELU) against the reference's DecoderQuerySplitter output."""
+    from oracle import harness
+    d = golden("f8_decode_split.npz")
+    pos = harness.decode(d.group("p"), harness.DecoderShape(num_block_cross=1, act="gelu_tanh"), d["z"], d["entities"])
+    assert rel_l2(pos, d["pos"]) < 2e-6

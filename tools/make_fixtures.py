@@ -15,6 +15,7 @@ Fixture families:
   f5_cond.npz       setup_conditioning, executed from the reference source via ast extraction
   f6_decode.npz     frozen stage-1 decode of latents -> positions (MD17 decoder shape, seeded weights)
   f7_encode.npz     frozen stage-1 Encoder + quant with a ragged entity mask (MD17 encoder shape, 48 latents)
+  f8_decode_split.npz  DecoderQuerySplitter (peptide decoder: 1x1-conv latent extender), one latent<-query cross block, tanh GELU
 """
 import ast
 import os
@@ -411,7 +412,33 @@ def f7():
     npz("f7_encode.npz", p=p, x=x, entities=ent, mask=mask, z=z)
 
 
+# ------------------------------------------------------------------------------------------- F8
+def f8():
+    from functools import partial
+    from src.models.components.decoder import DecoderQuerySplitter
+    ds = harness.DecoderShape(num_block_cross=1)
+    torch.manual_seed(11)
+    emb = EntityEmbeddingOrthogonal(n_entiy_embeddings=ds.n_entities, embedding_dim=128, max_norm=1)
+    dec = DecoderQuerySplitter(outputs={"pos": 3}, dim_query=128, dim_latent=32, entity_embedding=emb, dim_head_cross=16, dim_head_latent=16,
+                               num_head_cross=8, num_head_latent=2, num_block_cross=1, num_block_attn=1, qk_norm=True,
+                               act=partial(torch.nn.GELU, approximate="tanh"), num_split=4).eval()
+    post_quant = torch.nn.Sequential(torch.nn.LayerNorm(32, elementwise_affine=False), torch.nn.Linear(32, 32)).eval()
+    emb.embedding.weight.mul_(torch.linspace(0.5, 1.8, ds.n_entities)[:, None])
+    p = {"post_quant.1.weight": post_quant[1].weight.clone(), "post_quant.1.bias": post_quant[1].bias.clone()}
+    p.update({"decoder." + k: v.clone() for k, v in dec.state_dict().items()})
+    g = torch.Generator().manual_seed(12)
+    z = torch.randn(3, 24, 32, generator=g)
+    ent = torch.stack([torch.randperm(ds.n_entities, generator=g)[:14] for _ in range(3)])
+    with torch.no_grad():
+        pos = dec(post_quant(z), ent)["pos"]
+    mine = harness.decode(p, harness.DecoderShape(num_block_cross=1, act="gelu_tanh"), z, ent)
+    e = rel(mine, pos)
+    print(f"F8 decode (query splitter, cross block, tanh GELU): oracle rel {e:.2e}")
+    assert e < 2e-6
+    npz("f8_decode_split.npz", p=p, z=z, entities=ent, pos=pos)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8"]
     for w in which:
         globals()[w]()
