@@ -515,3 +515,27 @@ struct EpiLinear2 {
         }
     }
 };
+
+
+// The piece form of an epilogue (Epi::fetch / Epi::piece, written for k_gemm_pp.cuh) run back to back as the epilogue of the
+// one-tile-at-a-time kernel: 4 KiB of staging per wave instead of 8, which is what lets a PERSISTENT 256 x 256 kernel hold two
+// 64-deep k-tiles (128 KiB) plus the staging of its 8 waves in the 160 KiB of LDS, and the software prefetch of the next
+// piece's LDS rows / tables.  Wave tile must be 128 features x 64 tokens.
+template <class E>
+struct EpiPieces : E {
+    __host__ __device__ EpiPieces(const E &e) : E(e) {}
+
+    template <int WF, int WT>
+    static constexpr size_t wave_stage_bytes() { return E::pp_stage_bytes; }
+
+    template <int MI, int NJ>
+    __device__ __forceinline__ void run(f32x16 (&acc)[MI][NJ], char *stage, int f_wave, int n_wave, int lane, int F, int N) const {
+        static_assert(MI == 4 && NJ == 2, "piece form: 128 x 64 wave tiles");
+        typename E::Pipe k;
+        E::template fetch<0>(acc, stage, f_wave, n_wave, lane, F, N, k);
+#define LSL_P(C) E::template piece<C>(acc, stage, f_wave, n_wave, lane, F, N, k);
+        LSL_P(0) LSL_P(1) LSL_P(2) LSL_P(3) LSL_P(4) LSL_P(5) LSL_P(6) LSL_P(7)
+        LSL_P(8) LSL_P(9) LSL_P(10) LSL_P(11) LSL_P(12) LSL_P(13) LSL_P(14) LSL_P(15)
+#undef LSL_P
+    }
+};
