@@ -257,7 +257,7 @@ def main():
         else f"sampled trajectories/sec ({args.workload})",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 MFMA operands, fp32 accumulate/state", "data": "synthetic (seeded random weights and latents)",
+        "dtype": "bf16", "dtype_detail": "bf16 MFMA operands (linear1, linear2, attention), fp32 accumulators / residual state / small GEMMs", "data": "synthetic (seeded random weights and latents)",
         "config": {"workload": args.workload, "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
                    "mlp_ratio": kw["mlp_ratio"], "sampler": method, "state_updates": n_evals, "batch_per_gpu": B,
                    "global_batch": B * world, "trajectories_per_pass": pass_size,

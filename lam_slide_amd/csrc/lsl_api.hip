@@ -254,8 +254,8 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     if (variant == 20 && pp_ok && launch_gemm_pp<32, 4>(g, epi, st)) return;
     if (variant == 21 && pp_ok && launch_gemm_pp<64, 2>(g, epi, st)) return;
     if (variant == 22 && pp_ok && launch_gemm_pp<64, 3>(g, epi, st)) return;
-    if (variant == 7 && F % 32 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, EpiPieces<Epi>(epi), st);  // persistent, 64-deep k-tiles, piece epilogue
-    if (variant == 8 && F % 32 == 0) return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, EpiPieces<Epi>(epi), st);  // variant 6 with the piece epilogue
+    if (variant == 7 && F % 32 == 0 && pp_ok) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, EpiPieces<Epi>(epi), st);  // persistent, 64-deep k-tiles, piece epilogue
+    if (variant == 8 && F % 32 == 0 && pp_ok) return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, EpiPieces<Epi>(epi), st);  // variant 6 with the piece epilogue
     switch (variant) {
         case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
