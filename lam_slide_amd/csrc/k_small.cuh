@@ -406,3 +406,104 @@ __global__ void __launch_bounds__(256) k_head_step(float *x, float *out, const f
         }
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// Output head + state update, fp32 MFMA form.  Same contract as k_head_step; the [32 tokens x D] x [D x 32 channels] product runs on
+// v_mfma_f32_32x32x2_f32 (exact fp32 multiply-add, 1/16 of the bf16 rate - ample here) instead of LDS-fed scalar FMAs, which were
+// LDS-bandwidth bound (5 ds_read_b128 per 16 FMAs, 82 KB of LDS reads per token).  The four waves split k; W^T fragments stay in
+// registers across token tiles (C <= 32); the next tile's h rows are requested before the current tile's product, so the single
+// workgroup a CU holds never waits on HBM with nothing else to do.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <int NE>
+constexpr size_t head_mfma_lds_bytes() { return (size_t)HEAD_TOK * (NE * 64 + 4) * 4 + (size_t)4 * 32 * 33 * 4; }
+
+template <int NE, int VEC>
+__global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, const float *h, const float *shift, const float *scale,
+                                                        int mod_stride, const float *Wo, const float *bo, int N, int C, int tokens_per_traj,
+                                                        int do_step, float ax, float am, float aw, const float *noise, unsigned long long seed,
+                                                        unsigned step, unsigned long long elem_offset, float *trace) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = NE * 64, AS = D + 4, RPW = HEAD_TOK / 4, KW = D / 4, JS = KW / 8;  // k range per wave, 8-deep steps per wave
+    float *As = reinterpret_cast<float *>(smem);  // [HEAD_TOK][AS]  LayerNorm'ed + modulated rows
+    float *Ps = As + HEAD_TOK * AS;               // [4][32][33]     per-wave partial products (token, channel)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int tk = tid >> 3, cg = tid & 7;
+    const int n_tiles = (N + HEAD_TOK - 1) / HEAD_TOK;
+    const bool w_resident = C <= 32;
+
+    float4 wf[JS];  // B operand: W^T[k][channel r] for this wave's k range, lane (r, hf) holds k = 8 j + 4 hf .. + 3
+    auto load_w = [&](int c0) {
+        const int c = c0 + r;
+#pragma unroll
+        for (int j = 0; j < JS; ++j)
+            wf[j] = c < C ? *reinterpret_cast<const float4 *>(Wo + (size_t)c * D + wave * KW + 8 * j + 4 * hf) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (w_resident) load_w(0);
+
+    float v[RPW][NE];
+    auto load_rows = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) row_load<NE, VEC>(h + (size_t)min(tile * HEAD_TOK + wave + 4 * i, N - 1) * D, lane, v[i]);
+    };
+    if ((int)blockIdx.x < n_tiles) load_rows(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int n0 = tile * HEAD_TOK;
+        __syncthreads();  // the previous tile has finished with As and Ps
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int n = min(n0 + wave + 4 * i, N - 1);
+            float mean, rstd;
+            row_stats<NE>(v[i], 1e-6f, mean, rstd);
+            const size_t mo = (size_t)(n / tokens_per_traj) * mod_stride;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int d = row_col<NE, VEC>(lane, k);
+                As[(wave + 4 * i) * AS + d] = (v[i][k] - mean) * rstd * (1.0f + scale[mo + d]) + shift[mo + d];
+            }
+        }
+        if (tile + (int)gridDim.x < n_tiles) load_rows(tile + gridDim.x);  // in flight during the product below
+        __syncthreads();
+        const int n = n0 + tk;
+        for (int c0 = 0; c0 < C; c0 += 32) {
+            if (!w_resident) load_w(c0);
+            f32x16_t acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            const float *ar = As + r * AS + wave * KW + 4 * hf;
+#pragma unroll
+            for (int j = 0; j < JS; ++j) {
+                const float4 av = *reinterpret_cast<const float4 *>(ar + 8 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wf[j].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wf[j].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wf[j].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[j].w, acc, 0, 0, 0);
+            }
+            if (c0) __syncthreads();  // the previous slab's partials have been consumed
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Ps[(wave * 32 + acc_row(e, hf)) * 33 + r] = acc[e];
+            __syncthreads();
+            if (n < N) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cl = 4 * cg + j, c = c0 + cl;
+                    if (c < C) {
+                        const float m = ((Ps[(0 * 32 + tk) * 33 + cl] + Ps[(1 * 32 + tk) * 33 + cl]) + Ps[(2 * 32 + tk) * 33 + cl]) +
+                                        Ps[(3 * 32 + tk) * 33 + cl] + bo[c];
+                        const size_t e = (size_t)n * C + c;
+                        if (do_step) {
+                            float xn = ax * x[e] + am * m;
+                            if (aw != 0.0f) xn += aw * (noise ? noise[e] : philox_normal(seed, step, elem_offset + e));
+                            x[e] = xn;
+                            if (trace) trace[e] = xn;
+                        } else {
+                            out[e] = m;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}

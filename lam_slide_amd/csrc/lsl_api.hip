@@ -132,10 +132,23 @@ template <int NE, int VEC>
 void launch_ln_inplace_t(float *h, int n, float eps, hipStream_t st) {
     hipLaunchKernelGGL((k_ln_inplace<NE, VEC>), dim3((n + 3) / 4), dim3(256), 0, st, h, n, eps);
 }
+int device_cus();
+int env_int(const char *name, int dflt);
+
 template <int NE, int VEC>
 void launch_head_t(float *x, float *out, const float *h, const float *shift, const float *scale, int stride, const float *Wo,
                    const float *bo, int n, int C, int tpt, int do_step, float ax, float am, float aw, const float *noise,
                    unsigned long long seed, unsigned step, unsigned long long eo, float *trace, hipStream_t st) {
+    static const int mfma = env_int("LSL_HEAD_MFMA", 1);  // 0: the scalar-FMA kernel (A/B measurements)
+    if (mfma) {
+        auto kern = k_head_step_mfma<NE, VEC>;
+        constexpr size_t lds = head_mfma_lds_bytes<NE>();
+        static bool once = (allow_lds(kern, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, device_cus())), dim3(256), lds, st, x, out, h, shift, scale, stride,
+                           Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
+        return;
+    }
     auto kern = k_head_step<NE, VEC>;
     constexpr size_t lds = head_lds_bytes<NE>();
     static bool once = (allow_lds(kern, lds), true);
