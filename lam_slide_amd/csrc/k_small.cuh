@@ -157,34 +157,47 @@ __global__ void __launch_bounds__(256) k_embed(float *out, const float *in, cons
         float b0[ND];
 #pragma unroll
         for (int j = 0; j < ND; ++j) b0[j] = MODE == 0 ? bias[d + j] + bias2[d + j] : 0.0f;
-#pragma unroll 2
-        for (int tkn = tg; tkn < ntok; tkn += groups) {
-            const size_t row = (size_t)(n0 + tkn) * D + d;
-            float add[ND], acc[ND];
-            if (MODE == 0) {
-                const float *me = mask_emb + (mask[n0 + tkn] != 0 ? D : 0) + d;
+        // tokens in groups of PF: the group's `base` rows (the only HBM reads of the loop) are all requested before the first
+        // product, so PF loads are in flight per thread instead of one or two
+        constexpr int PF = 4;
+        for (int t0 = tg; t0 < ntok; t0 += PF * groups) {
+            float add[PF][ND];
 #pragma unroll
-                for (int j = 0; j < ND; ++j) add[j] = b0[j] + me[j];
-            } else {
+            for (int u = 0; u < PF; ++u) {
+                const int tkn = min(t0 + u * groups, ntok - 1);
+                const size_t row = (size_t)(n0 + tkn) * D + d;
+                if (MODE == 0) {
+                    const float *me = mask_emb + (mask[n0 + tkn] != 0 ? D : 0) + d;
 #pragma unroll
-                for (int j = 0; j < ND; ++j) add[j] = base[row + j];
+                    for (int j = 0; j < ND; ++j) add[u][j] = b0[j] + me[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) add[u][j] = base[row + j];
+                }
             }
 #pragma unroll
-            for (int j = 0; j < ND; ++j) acc[j] = 0.0f;
+            for (int u = 0; u < PF; ++u) {
+                const int tkn = t0 + u * groups;
+                if (tkn >= ntok) break;
+                const size_t row = (size_t)(n0 + tkn) * D + d;
+                float acc[ND];
 #pragma unroll
-            for (int c = 0; c < CMAX; c += 4) {
-                const float4 xv = *reinterpret_cast<const float4 *>(&xs[tkn][c]);
+                for (int j = 0; j < ND; ++j) acc[j] = 0.0f;
 #pragma unroll
-                for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.x, w[j][c], acc[j]);
+                for (int c = 0; c < CMAX; c += 4) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(&xs[tkn][c]);
 #pragma unroll
-                for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.y, w[j][c + 1], acc[j]);
+                    for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.x, w[j][c], acc[j]);
 #pragma unroll
-                for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.z, w[j][c + 2], acc[j]);
+                    for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.y, w[j][c + 1], acc[j]);
 #pragma unroll
-                for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.w, w[j][c + 3], acc[j]);
+                    for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.z, w[j][c + 2], acc[j]);
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.w, w[j][c + 3], acc[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < ND; ++j) out[row + j] = acc[j] + add[u][j];
             }
-#pragma unroll
-            for (int j = 0; j < ND; ++j) out[row + j] = acc[j] + add[j];
         }
     }
 }
