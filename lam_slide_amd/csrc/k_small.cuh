@@ -138,65 +138,71 @@ __global__ void __launch_bounds__(256) k_embed(float *out, const float *in, cons
                                                const float *bias2, const float *mask_emb, const int64_t *mask,
                                                const float *base, int N, int C, int D) {
     __shared__ __attribute__((aligned(16))) float xs[EMB_TOK][CMAX];
-    const int n0 = blockIdx.x * EMB_TOK;
-    const int ntok = min(EMB_TOK, N - n0);
-    for (int i = threadIdx.x; i < EMB_TOK * CMAX; i += 256) {
-        const int tkn = i / CMAX, c = i % CMAX;
-        xs[tkn][c] = (tkn < ntok && c < C) ? in[(size_t)(n0 + tkn) * C + c] : 0.0f;
-    }
+    const int n_tiles = (N + EMB_TOK - 1) / EMB_TOK;
     const int DQ = D / ND, groups = DQ >= 256 ? 1 : 256 / DQ;
-    __syncthreads();
+    // persistent workgroups: a thread's weight rows are fetched once and stay in registers while it walks the token tiles
     for (int dq = threadIdx.x % (DQ < 256 ? DQ : 256); dq < DQ; dq += 256) {
         const int tg = DQ >= 256 ? 0 : threadIdx.x / DQ, d = ND * dq;
-        if (tg >= groups) break;
+        const bool active = tg < groups;  // (threads beyond groups * DQ only help with the staging)
         float w[ND][CMAX];
 #pragma unroll
         for (int j = 0; j < ND; ++j)
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) w[j][c] = c < C ? W[(size_t)(d + j) * C + c] : 0.0f;
+            for (int c = 0; c < CMAX; ++c) w[j][c] = (active && c < C) ? W[(size_t)(d + j) * C + c] : 0.0f;
         float b0[ND];
 #pragma unroll
-        for (int j = 0; j < ND; ++j) b0[j] = MODE == 0 ? bias[d + j] + bias2[d + j] : 0.0f;
-        // tokens in groups of PF: the group's `base` rows (the only HBM reads of the loop) are all requested before the first
-        // product, so PF loads are in flight per thread instead of one or two
-        constexpr int PF = 4;
-        for (int t0 = tg; t0 < ntok; t0 += PF * groups) {
-            float add[PF][ND];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int tkn = min(t0 + u * groups, ntok - 1);
-                const size_t row = (size_t)(n0 + tkn) * D + d;
-                if (MODE == 0) {
-                    const float *me = mask_emb + (mask[n0 + tkn] != 0 ? D : 0) + d;
-#pragma unroll
-                    for (int j = 0; j < ND; ++j) add[u][j] = b0[j] + me[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < ND; ++j) add[u][j] = base[row + j];
-                }
+        for (int j = 0; j < ND; ++j) b0[j] = (MODE == 0 && active) ? bias[d + j] + bias2[d + j] : 0.0f;
+        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            const int n0 = tile * EMB_TOK;
+            const int ntok = min(EMB_TOK, N - n0);
+            __syncthreads();  // the previous tile's products have finished reading xs
+            for (int i = threadIdx.x; i < EMB_TOK * CMAX; i += 256) {
+                const int tkn = i / CMAX, c = i % CMAX;
+                xs[tkn][c] = (tkn < ntok && c < C) ? in[(size_t)(n0 + tkn) * C + c] : 0.0f;
             }
+            __syncthreads();
+            if (!active) continue;
+            // tokens in groups of PF: the group's `base` rows (the only HBM reads of the loop) are all requested before the first
+            // product, so PF loads are in flight per thread instead of one or two
+            constexpr int PF = 4;
+            for (int t0 = tg; t0 < ntok; t0 += PF * groups) {
+                float add[PF][ND];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int tkn = t0 + u * groups;
-                if (tkn >= ntok) break;
-                const size_t row = (size_t)(n0 + tkn) * D + d;
-                float acc[ND];
+                for (int u = 0; u < PF; ++u) {
+                    const int tkn = min(t0 + u * groups, ntok - 1);
+                    const size_t row = (size_t)(n0 + tkn) * D + d;
+                    if (MODE == 0) {
+                        const float *me = mask_emb + (mask[n0 + tkn] != 0 ? D : 0) + d;
 #pragma unroll
-                for (int j = 0; j < ND; ++j) acc[j] = 0.0f;
+                        for (int j = 0; j < ND; ++j) add[u][j] = b0[j] + me[j];
+                    } else {
 #pragma unroll
-                for (int c = 0; c < CMAX; c += 4) {
-                    const float4 xv = *reinterpret_cast<const float4 *>(&xs[tkn][c]);
-#pragma unroll
-                    for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.x, w[j][c], acc[j]);
-#pragma unroll
-                    for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.y, w[j][c + 1], acc[j]);
-#pragma unroll
-                    for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.z, w[j][c + 2], acc[j]);
-#pragma unroll
-                    for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.w, w[j][c + 3], acc[j]);
+                        for (int j = 0; j < ND; ++j) add[u][j] = base[row + j];
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < ND; ++j) out[row + j] = acc[j] + add[u][j];
+                for (int u = 0; u < PF; ++u) {
+                    const int tkn = t0 + u * groups;
+                    if (tkn >= ntok) break;
+                    const size_t row = (size_t)(n0 + tkn) * D + d;
+                    float acc[ND];
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) acc[j] = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; c += 4) {
+                        const float4 xv = *reinterpret_cast<const float4 *>(&xs[tkn][c]);
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.x, w[j][c], acc[j]);
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.y, w[j][c + 1], acc[j]);
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.z, w[j][c + 2], acc[j]);
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.w, w[j][c + 3], acc[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) out[row + j] = acc[j] + add[u][j];
+                }
             }
         }
     }

@@ -169,10 +169,12 @@ void launch_head_t(float *x, float *out, const float *h, const float *shift, con
         default: FN<8, 2>(__VA_ARGS__); break;          \
     }
 
+int device_cus();
+
 template <int MODE>
 int launch_embed(float *out, const float *in, const float *W, const float *b, const float *b2, const float *me,
                  const int64_t *mask, const float *base, int n, int C, int D, hipStream_t st) {
-    const dim3 grid((n + EMB_TOK - 1) / EMB_TOK), blk(256);
+    const dim3 grid(std::min((n + EMB_TOK - 1) / EMB_TOK, 2 * device_cus())), blk(256);  // persistent: weights fetched once per workgroup
     if (C <= 32) hipLaunchKernelGGL((k_embed<32, MODE, 4>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
     else if (C <= 64) hipLaunchKernelGGL((k_embed<64, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
     else if (C <= 96) hipLaunchKernelGGL((k_embed<96, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
