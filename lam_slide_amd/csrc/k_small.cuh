@@ -295,6 +295,52 @@ __global__ void __launch_bounds__(256) k_ln_modulate(u16 *a, const float *h, con
     }
 }
 
+// The same operation for D a multiple of 256, persistent: a wave walks tokens gw, gw + (waves in the grid), ... with the next
+// row already requested (16-byte loads, 1 KiB per wave instruction) while the current one is reduced and written (8-byte
+// bf16x4 stores).  HBM-bound: 2 KB read + 1 KB written per token.
+template <int NE>
+__global__ void __launch_bounds__(256) k_ln_modulate_v4(u16 *a, const float *h, const float *shift, const float *scale, int mod_stride,
+                                                        int N, int tokens_per_traj) {
+    static_assert(NE % 4 == 0, "D must be a multiple of 256");
+    constexpr int D = NE * 64, Q = NE / 4;
+    constexpr float invD = 1.0f / (float)D;
+    const int lane = threadIdx.x & 63;
+    const int stride = gridDim.x * 4;
+    int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float4 v[Q], vn[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) v[k] = *reinterpret_cast<const float4 *>(h + (size_t)n * D + 4 * lane + 256 * k);
+    for (; n < N; n += stride) {
+        const int nn = n + stride < N ? n + stride : n;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) vn[k] = *reinterpret_cast<const float4 *>(h + (size_t)nn * D + 4 * lane + 256 * k);
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        const float mean = wave_sum(s) * invD;
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invD + 1e-6f);
+        const size_t mo = (size_t)(n / tokens_per_traj) * mod_stride;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            const int d = 4 * lane + 256 * k;
+            const float4 sc = *reinterpret_cast<const float4 *>(scale + mo + d);
+            const float4 sf = *reinterpret_cast<const float4 *>(shift + mo + d);
+            const u32x2 pk = {pack2((v[k].x - mean) * rstd * (1.0f + sc.x) + sf.x, (v[k].y - mean) * rstd * (1.0f + sc.y) + sf.y),
+                              pack2((v[k].z - mean) * rstd * (1.0f + sc.z) + sf.z, (v[k].w - mean) * rstd * (1.0f + sc.w) + sf.w)};
+            *reinterpret_cast<u32x2 *>(a + (size_t)n * D + d) = pk;
+        }
+#pragma unroll
+        for (int k = 0; k < Q; ++k) v[k] = vn[k];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller: standard normal for (seed, step, element).  Documented stream:
 // counter = (elem/4 lo, elem/4 hi, step, 0), key = (seed lo, seed hi); element e takes output e % 4

@@ -124,8 +124,19 @@ void allow_lds(K kernel, size_t bytes) {
 
 // ---- launch helpers -------------------------------------------------------------------------------
 
+int device_cus();
+int env_int(const char *name, int dflt);
+
 template <int NE, int VEC>
 void launch_ln_mod_t(u16 *a, const float *h, const float *shift, const float *scale, int stride, int n, int tpt, hipStream_t st) {
+    if constexpr (NE % 4 == 0) {
+        static const int persist = env_int("LSL_LN_PERSIST", 16);  // workgroups per CU of the persistent form; 0 = one wave per token
+        if (persist > 0) {
+            const int grid = std::min((n + 3) / 4, device_cus() * persist);
+            hipLaunchKernelGGL((k_ln_modulate_v4<NE>), dim3(grid), dim3(256), 0, st, a, h, shift, scale, stride, n, tpt);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_ln_modulate<NE, VEC>), dim3((n + 3) / 4), dim3(256), 0, st, a, h, shift, scale, stride, n, tpt);
 }
 template <int NE, int VEC>
