@@ -204,14 +204,13 @@ __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
 
     for (int qt = wsub; qt < nqt; qt += WPI) {
         bf16x8 qf[KS];
-        if (qt == wsub) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) qf[s] = qf0[s];
-        } else {
-            const int qpos = min(qt * 32 + r, S - 1);
+        for (int s = 0; s < KS; ++s) qf[s] = qf0[s];
+        if (qt + WPI < nqt) {  // the next query tile of this wave is requested now and consumed one iteration later
+            const int qpos = min((qt + WPI) * 32 + r, S - 1);
             const u16 *qrow = a.qkv + (tok0 + (size_t)qpos * a.pos_stride) * rs + head * HDP;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) qf[s] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qrow + 16 * s + 8 * hf));
+            for (int s = 0; s < KS; ++s) qf0[s] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qrow + 16 * s + 8 * hf));
         }
 
         // pass 1: row maximum only (scores are recomputed in pass 2: two extra MFMAs per tile are far cheaper than
