@@ -215,8 +215,8 @@ __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
 
         // pass 1: row maximum only (scores are recomputed in pass 2: two extra MFMAs per tile are far cheaper than
         // keeping 16 * NKT score registers live, which costs the occupancy that hides the LDS / exp latencies)
-        auto scores = [&](int kt) {
-            f32x16 t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(kt * 32 + r, hf))), qf[0], zero);
+        auto scores = [&](int kt, const f32x16 &init) {
+            f32x16 t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(kt * 32 + r, hf))), qf[0], init);
             if (KS == 2)
                 t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(kt * 32 + r, 2 + hf))), qf[KS - 1], t);
             if (kt * 32 + 32 > S) {  // wave-uniform: zero-padded keys of the last tile do not take part
@@ -229,22 +229,25 @@ __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
         float mx = -INFINITY;
 #pragma unroll 2
         for (int kt = 0; kt < nkt; ++kt) {
-            const f32x16 t = scores(kt);
+            const f32x16 t = scores(kt, zero);
 #pragma unroll
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[e]);
         }
         mx = fmaxf(mx, xhalf(mx));
-        float sum = 0.0f;
-        f32x16 o = zero;
+        // pass 2: the row maximum is subtracted by the MFMA itself (accumulator preset to -max), and the row sum comes out of a
+        // third MFMA against an all-ones operand (sum over keys of the SAME bf16 probabilities that multiply V) - two VALU
+        // operations less per score element, and this kernel is VALU-bound at head_dim 32
+        f32x16 negmx;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negmx[e] = -mx;
+        const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // eight bf16 1.0
+        f32x16 o = zero, lsum = zero;
 #pragma unroll 2
         for (int kt = 0; kt < nkt; ++kt) {
-            const f32x16 t = scores(kt);
+            const f32x16 t = scores(kt, negmx);
             float p[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                p[e] = __builtin_amdgcn_exp2f(t[e] - mx);
-                sum += p[e];
-            }
+            for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(t[e]);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 u32x4 pw = {pack2(p[8 * s], p[8 * s + 1]), pack2(p[8 * s + 2], p[8 * s + 3]),
@@ -255,9 +258,10 @@ __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 o = mfma32(__builtin_bit_cast(bf16x8, vv), as_bf16x8(pw), o);
+                lsum = mfma32(as_bf16x8(ones_w), as_bf16x8(pw), lsum);  // every row = sum over this tile's keys, column = query
             }
         }
-        const float inv_l = 1.0f / (sum + xhalf(sum));
+        const float inv_l = 1.0f / lsum[0];
         const int qglob = qt * 32 + r;
         if (qglob < S && item_ok) {
             u16 *dst = a.z + (tok0 + (size_t)qglob * a.pos_stride) * a.zw + head * HDP;
