@@ -400,3 +400,38 @@ def test_stage1_decode_query_splitter_cross_block_tanh(golden, dev):
     err = rel_l2(pos, d["pos"])
     print(f"stage-1 decode (query splitter) rel L2 {err:.3e}")
     assert err < 1e-5
+
+
+RANDOM_SHAPES = {
+    # name: (NetShape kwargs, B, T, L)      edge cases beyond the reference-generated shape classes
+    "one_token": (dict(depth=1, in_dim=8, hidden_size=64, num_heads=4, mlp_ratio=2), 1, 1, 1),
+    "d320_hd32_odd_tiles": (dict(depth=2, in_dim=32, hidden_size=320, num_heads=10, mlp_ratio=2), 3, 7, 19),
+    "d448_hd28_padded": (dict(depth=1, in_dim=16, hidden_size=448, num_heads=16, mlp_ratio=1), 2, 5, 9),
+    "c96_d192": (dict(depth=2, in_dim=96, hidden_size=192, num_heads=12, mlp_ratio=4), 2, 33, 2),
+    "long_axis_257": (dict(depth=1, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2), 1, 257, 3),
+    "long_axis_300_y_norm": (dict(depth=1, in_dim=32, hidden_size=256, num_heads=8, mlp_ratio=2, vec_in_dim=24, normalize=True), 2, 3, 300),
+    "c64_d512_ragged_tokens": (dict(depth=1, in_dim=64, hidden_size=512, num_heads=16, mlp_ratio=2), 5, 3, 21),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RANDOM_SHAPES))
+def test_forward_edge_shapes_vs_oracle(name, dev):
+    """One network evaluation against the oracle (itself pinned to the reference) on shapes the shipped configs do not hit: a single
+    token, odd k-tile / feature-tile counts, padded head widths, C up to 96, attended axes just above 256 (LDS tile limit of
+    the short-sequence kernel), token counts that are not multiples of any tile."""
+    from oracle import latent_net
+    kw, B, T, L = RANDOM_SHAPES[name]
+    sh = latent_net.NetShape(**kw)
+    p = latent_net.random_params(sh, seed=11)
+    net = build_net(sh, p, dev)
+    g = torch.Generator().manual_seed(5)
+    x, xc = torch.randn(B, T, L, sh.in_dim, generator=g), torch.randn(B, T, L, sh.in_dim, generator=g)
+    mask = (torch.rand(B, T, L, generator=g) < 0.4).long()
+    t = torch.rand(B, generator=g)
+    y = torch.randn(B, sh.vec_in_dim, generator=g) if sh.vec_in_dim else None
+    want = latent_net.forward(p, sh, x, t, xc, mask, y)
+    got = net(x.to(dev), t.to(dev), xc.to(dev), mask.to(dev), y.to(dev) if y is not None else None).cpu()
+    err = rel_l2(got, want)
+    print(f"{name}: rel L2 {err:.3e}")
+    assert net.last_path == "hip" and torch.isfinite(got).all()
+    assert err < 5e-3, (name, err)
