@@ -75,6 +75,19 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return fmaf(-ax, p * t * e, relu);
 }
 
+// Streaming ("nt") stores: the line is written out without staying resident in L2.  The GEMM epilogues write 0.5-1.3 GB per
+// launch through the 4 MiB L2 of each XCD; with plain stores that evicted the operand tiles every round (linear1 fetched
+// 1.1 GB per launch for 0.25 GB of operands; with nt stores 0.32 GB).  Inline asm on purpose: when a branch selects between
+// __builtin_nontemporal_store and a plain store of the same value, hipcc merges the two and drops the hint.
+__device__ __forceinline__ void store16(void *p, u32x4 v, bool nt) {
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<u32x4 *>(p) = v;
+}
+__device__ __forceinline__ void store8(void *p, u32x2 v, bool nt) {
+    if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<u32x2 *>(p) = v;
+}
+
 // Workgroup id remap so that consecutive logical tiles share an XCD's L2.  Hardware deals
 // workgroups round-robin over the 8 XCDs; this only affects speed, never results.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

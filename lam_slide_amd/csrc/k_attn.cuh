@@ -22,6 +22,7 @@ struct AttnArgs {
     int n_seq;       // number of sequences
     // token of (seq, pos) = (seq / inner) * outer_stride + (seq % inner) + pos * pos_stride
     int inner, outer_stride, pos_stride;
+    int nt;          // streaming stores for the output (common.cuh: store8)
 };
 
 template <int HDP>
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(NW * 64) k_attention(AttnArgs a) {
 #pragma unroll
             for (int q4 = 0; q4 < HDP / 8; ++q4) {
                 u32x2 pk = {pack2(o[4 * q4] * inv_l, o[4 * q4 + 1] * inv_l), pack2(o[4 * q4 + 2] * inv_l, o[4 * q4 + 3] * inv_l)};
-                *reinterpret_cast<u32x2 *>(dst + 8 * q4 + 4 * hf) = pk;
+                store8(dst + 8 * q4 + 4 * hf, pk, a.nt);
             }
         }
     }
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
 #pragma unroll
             for (int q4 = 0; q4 < HDP / 8; ++q4) {
                 u32x2 pk = {pack2(o[4 * q4] * inv_l, o[4 * q4 + 1] * inv_l), pack2(o[4 * q4 + 2] * inv_l, o[4 * q4 + 3] * inv_l)};
-                *reinterpret_cast<u32x2 *>(dst + 8 * q4 + 4 * hf) = pk;
+                store8(dst + 8 * q4 + 4 * hf, pk, a.nt);
             }
         }
     }

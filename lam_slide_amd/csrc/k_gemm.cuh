@@ -233,7 +233,8 @@ struct EpiLinear1 {
     unsigned div_magic, mod_magic;  // floor(2^32 / d) + 1 for d = pos_div, pos_mod (0 when d == 1): n / d == umulhi(n, magic) for n * d < 2^32
     float inv_hd;          // 1 / true head_dim
     float q_premul;        // head_dim^-0.5 * log2(e), folded into q for the exp2-based softmax
-    int probe;             // TIMING PROBES ONLY (results wrong): bit3 skip norm/RoPE/GELU math, bit4 skip the global stores
+    int probe;             // TIMING PROBES ONLY (results wrong): bit3 skip norm/RoPE/GELU math, bit4 skip the global stores;
+                           // bit5 (set by the launcher, results unchanged): streaming stores
 
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return (size_t)64 * 32 * 4; }
@@ -307,7 +308,7 @@ struct EpiLinear1 {
                     if (f_ok && n < N && !(probe & 16)) {
                         const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
                         u16 *dst = sec_out < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
-                        *reinterpret_cast<u32x4 *>(dst) = pk;
+                        store16(dst, pk, probe & 32);
                     }
                 }
             }
@@ -405,7 +406,7 @@ struct EpiLinear1 {
         if (f_ok && n < N && !(probe & 16)) {
             const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
             u16 *dst = sec_out < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
-            *reinterpret_cast<u32x4 *>(dst) = pk;
+            store16(dst, pk, probe & 32);
         }
     }
 };
@@ -416,7 +417,7 @@ struct EpiLinear2 {
     const float *gate;  // mods + gate offset, row stride mod_stride
     float *h;           // [N][D]
     int D, mod_stride, tokens_per_traj;
-    int probe;  // unused (same launcher as EpiLinear1)
+    int probe;  // bit5: streaming stores (set by the launcher)
     unsigned tpt_magic;  // floor(2^32 / tokens_per_traj) + 1 (0 when tokens_per_traj == 1): n / tokens_per_traj by multiply-high
 
     template <int WF, int WT>
@@ -454,7 +455,7 @@ struct EpiLinear2 {
                     hv.y = fmaf(gt.y, a.y + b.y, hv.y);
                     hv.z = fmaf(gt.z, a.z + b.z, hv.z);
                     hv.w = fmaf(gt.w, a.w + b.w, hv.w);
-                    *reinterpret_cast<float4 *>(hp) = hv;
+                    store16(hp, __builtin_bit_cast(u32x4, hv), probe & 32);
                 }
             }
         }
@@ -511,7 +512,7 @@ struct EpiLinear2 {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int n = n_wave + j * 32 + 16 * hb + 8 * it + (lane >> 3);
-            if (f < F && n < N) *reinterpret_cast<float4 *>(h + (size_t)n * D + f) = out[it];
+            if (f < F && n < N) store16(h + (size_t)n * D + f, __builtin_bit_cast(u32x4, out[it]), probe & 32);
         }
     }
 };

@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) k_ln_modulate(u16 *a, const float *h, con
 // bf16x4 stores).  HBM-bound: 2 KB read + 1 KB written per token.
 template <int NE>
 __global__ void __launch_bounds__(256) k_ln_modulate_v4(u16 *a, const float *h, const float *shift, const float *scale, int mod_stride,
-                                                        int N, int tokens_per_traj) {
+                                                        int N, int tokens_per_traj, int nt) {
     static_assert(NE % 4 == 0, "D must be a multiple of 256");
     constexpr int D = NE * 64, Q = NE / 4;
     constexpr float invD = 1.0f / (float)D;
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) k_ln_modulate_v4(u16 *a, const float *h, 
             const float4 sf = *reinterpret_cast<const float4 *>(shift + mo + d);
             const u32x2 pk = {pack2((v[k].x - mean) * rstd * (1.0f + sc.x) + sf.x, (v[k].y - mean) * rstd * (1.0f + sc.y) + sf.y),
                               pack2((v[k].z - mean) * rstd * (1.0f + sc.z) + sf.z, (v[k].w - mean) * rstd * (1.0f + sc.w) + sf.w)};
-            *reinterpret_cast<u32x2 *>(a + (size_t)n * D + d) = pk;
+            store8(a + (size_t)n * D + d, pk, nt);
         }
 #pragma unroll
         for (int k = 0; k < Q; ++k) v[k] = vn[k];

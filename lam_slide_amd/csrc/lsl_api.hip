@@ -133,7 +133,8 @@ void launch_ln_mod_t(u16 *a, const float *h, const float *shift, const float *sc
         static const int persist = env_int("LSL_LN_PERSIST", 16);  // workgroups per CU of the persistent form; 0 = one wave per token
         if (persist > 0) {
             const int grid = std::min((n + 3) / 4, device_cus() * persist);
-            hipLaunchKernelGGL((k_ln_modulate_v4<NE>), dim3(grid), dim3(256), 0, st, a, h, shift, scale, stride, n, tpt);
+            static const int nt = (env_int("LSL_NT", 3) >> 3) & 1;
+            hipLaunchKernelGGL((k_ln_modulate_v4<NE>), dim3(grid), dim3(256), 0, st, a, h, shift, scale, stride, n, tpt, nt);
             return;
         }
     }
@@ -274,8 +275,10 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     static const int probe = env_int("LSL_PROBE", 0);
     static const int stagger = env_int("LSL_STAGGER", 0);
     GemmArgs g{W, X, F, N, K, stagger, probe};
+    // LSL_NT bit 0: linear1 output, bit 1: linear2 residual update, bit 2: attention output, bit 3: LayerNorm+modulate output
+    static const int nt = env_int("LSL_NT", 3);
     Epi epi = epi_in;
-    epi.probe = probe;
+    epi.probe = probe | ((nt >> (std::is_same<Epi, EpiLinear2>::value ? 1 : 0)) & 1 ? 32 : 0);
     const bool pp_ok = !std::is_same<Epi, EpiLinear2>::value ? hhd % 32 == 0 : true;  // linear1 sections start on 32-feature tiles
     if (variant == 20 && pp_ok && launch_gemm_pp<32, 4>(g, epi, st)) return;
     if (variant == 21 && pp_ok && launch_gemm_pp<64, 2>(g, epi, st)) return;
@@ -418,7 +421,9 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
         launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st, m->HHD);
     }
     m->prof.end(0, st);
+    static const int nt_mask = env_int("LSL_NT", 3);
     AttnArgs aa;
+    aa.nt = (nt_mask >> 2) & 1;
     aa.qkv = ws.qkv;
     aa.z = ws.z;
     aa.HHD = m->HHD;
