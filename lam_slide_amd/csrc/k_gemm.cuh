@@ -406,7 +406,7 @@ struct EpiLinear1 {
         if (f_ok && n < N && !(probe & 16)) {
             const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
             u16 *dst = sec_out < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
-            store16(dst, pk, probe & 32);
+            *reinterpret_cast<u32x4 *>(dst) = pk;  // 64 contiguous bytes per token row: half lines, no streaming stores (they need whole lines)
         }
     }
 };

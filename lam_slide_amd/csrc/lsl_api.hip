@@ -261,7 +261,7 @@ bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 //   13 256x128  4 waves 32x2, persistent, two workgroups per CU
 //   15 256x256 16 waves 64x2 (64x64 per wave, 4 waves/SIMD: the light linear2 epilogue fits the 128-VGPR budget and the
 //      extra occupancy hides load / store latency)
-// 20-22: ping-pong halves (k_gemm_pp.cuh).  Default (-1): 6 for linear1, 7 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
+// 20-22: ping-pong halves (k_gemm_pp.cuh).  Default (-1): 5 for linear1 (6 when K is not a multiple of 64), 7 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
 // every variant that was tried, including the ones no longer compiled in).
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi_in, hipStream_t st, int hhd = 32) {
@@ -271,7 +271,7 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     const int forced = forced_one >= 0 ? forced_one : forced_all;
     // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
-    const int variant = forced >= 0 ? forced : ragged ? 10 : (std::is_same<Epi, EpiLinear2>::value ? (K % 64 == 0 ? 7 : 15) : 6);
+    const int variant = forced >= 0 ? forced : ragged ? 10 : (std::is_same<Epi, EpiLinear2>::value ? (K % 64 == 0 ? 7 : 15) : (K % 64 == 0 ? 5 : 6));
     static const int probe = env_int("LSL_PROBE", 0);
     static const int stagger = env_int("LSL_STAGGER", 0);
     GemmArgs g{W, X, F, N, K, stagger, probe};
