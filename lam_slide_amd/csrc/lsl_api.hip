@@ -258,6 +258,7 @@ bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 //   10 128x128  4 waves 32x3 (used when F is not a multiple of 256: D = 128 / 384 models)
 //   7  256x256  8 waves 64x2, persistent, piece-form epilogue (4 KiB staging per wave, next piece prefetched): linear2 default
 //   8  256x256  8 waves 32x3, persistent, piece-form epilogue
+//   11 128x128  4 waves 64x2
 //   13 256x128  4 waves 32x2, persistent, two workgroups per CU
 //   15 256x256 16 waves 64x2 (64x64 per wave, 4 waves/SIMD: the light linear2 epilogue fits the 128-VGPR budget and the
 //      extra occupancy hides load / store latency)
@@ -271,7 +272,8 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     const int forced = forced_one >= 0 ? forced_one : forced_all;
     // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
-    const int variant = forced >= 0 ? forced : ragged ? 10 : (std::is_same<Epi, EpiLinear2>::value ? (K % 64 == 0 ? 7 : 15) : (K % 64 == 0 ? 5 : 6));
+    const int ragged_variant = std::is_same<Epi, EpiLinear2>::value && K % 64 == 0 ? 11 : 10;  // measured on the D = 384 / 128 models
+    const int variant = forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 64 == 0 ? 7 : 15) : (K % 64 == 0 ? 5 : 6));
     static const int probe = env_int("LSL_PROBE", 0);
     static const int stagger = env_int("LSL_STAGGER", 0);
     GemmArgs g{W, X, F, N, K, stagger, probe};
@@ -288,6 +290,7 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     switch (variant) {
         case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
+        case 11: return launch_gemm_glds<128, 128, 2, 2, 64, 2, false>(g, epi, st);
         case 13: return launch_gemm_glds<256, 128, 2, 2, 32, 2, true>(g, epi, st);
         case 15: return launch_gemm_glds<256, 256, 4, 4, 64, 2, false>(g, epi, st);
         default: return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, epi, st);
