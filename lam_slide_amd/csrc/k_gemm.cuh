@@ -324,31 +324,24 @@ struct EpiLinear1 {
     struct Pipe {
         float4 lo, hi;          // staged sums of the 8 features
         float4 c0, c1;          // RoPE (cos, sin) of the 4 pairs
-        float4 b0, b1, s0, s1;  // bias, q/k scale
     };
     static constexpr int pieces = 16;
     static constexpr size_t pp_stage_bytes = 4096;
+    // lower bound of the vector-memory instructions piece<C> issues (bias 2 loads, [q/k scales 2,] next piece's RoPE row 2, store 1):
+    // what a counted s_waitcnt may leave outstanding when it only wants the LDS-DMA loads issued before the piece
+    static constexpr int piece_ops(bool last) { return last ? 3 : 5; }
 
-    template <int C>
-    __device__ __forceinline__ void fetch(f32x16 (&acc)[4][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
+    template <int C, int MI>
+    __device__ __forceinline__ void fetch(f32x16 (&acc)[MI][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
         constexpr int i = C >> 2, j = (C >> 1) & 1, hb = C & 1;
         const int r = lane & 31, hf = lane >> 5, tr = lane >> 2, c = lane & 3;
         const int f = f_wave + i * 32 + 8 * c;
         const int sec = (probe & 8) ? 2 : (f >= HHD) + (f >= 2 * HHD) + (f >= 3 * HHD);
         const int d = f & (HDP - 1);
         // every load below is unconditional (addresses clamped into the tables, unused values ignored by piece<C>): a load
-        // inside a divergent branch gets its s_waitcnt at the end of that branch, i.e. right here instead of one piece later
-        if (C % 4 == 0) {  // new feature tile
-            const int fc = min(f, F - 8);
-            k.b0 = *reinterpret_cast<const float4 *>(bias + fc);
-            k.b1 = *reinterpret_cast<const float4 *>(bias + fc + 4);
-            // both scale vectors, selected by value (a per-lane select of the two POINTERS becomes a dependent load of the pointer)
-            const float4 q0 = *reinterpret_cast<const float4 *>(qs + d), q1 = *reinterpret_cast<const float4 *>(qs + d + 4);
-            const float4 k0 = *reinterpret_cast<const float4 *>(ks + d), k1 = *reinterpret_cast<const float4 *>(ks + d + 4);
-            const bool isk = sec == 1;
-            k.s0 = make_float4(isk ? k0.x : q0.x, isk ? k0.y : q0.y, isk ? k0.z : q0.z, isk ? k0.w : q0.w);
-            k.s1 = make_float4(isk ? k1.x : q1.x, isk ? k1.y : q1.y, isk ? k1.z : q1.z, isk ? k1.w : q1.w);
-        }
+        // inside a divergent branch gets its s_waitcnt at the end of that branch, i.e. right here instead of one piece later.
+        // (bias and q/k scales are NOT carried in the pipe: 16 VGPRs that the drain kernel does not have; piece<C> reads them from
+        // L1 where it uses them)
         {
             const unsigned nn = (unsigned)min(n_wave + j * 32 + 16 * hb + tr, N - 1);
             const unsigned n1 = div_magic ? __umulhi(nn, div_magic) : nn;
@@ -369,8 +362,8 @@ struct EpiLinear1 {
         k.hi = *reinterpret_cast<const float4 *>(stage + swz_bk<64>(row, 2 * c + 1));
     }
 
-    template <int C>
-    __device__ __forceinline__ void piece(f32x16 (&acc)[4][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
+    template <int C, int MI>
+    __device__ __forceinline__ void piece(f32x16 (&acc)[MI][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
         constexpr int i = C >> 2, j = (C >> 1) & 1, hb = C & 1;
         const int tr = lane >> 2, c = lane & 3;
         const int f = f_wave + i * 32 + 8 * c;
@@ -378,11 +371,13 @@ struct EpiLinear1 {
         const int sec_out = (f >= HHD) + (f >= 2 * HHD) + (f >= 3 * HHD);  // 0 q, 1 k, 2 v, 3 mlp
         const int sec = (probe & 8) ? 2 : sec_out;
         const int n = n_wave + j * 32 + 16 * hb + tr;
-        float v[8] = {k.lo.x + k.b0.x, k.lo.y + k.b0.y, k.lo.z + k.b0.z, k.lo.w + k.b0.w,
-                      k.hi.x + k.b1.x, k.hi.y + k.b1.y, k.hi.z + k.b1.z, k.hi.w + k.b1.w};
-        const float4 c0 = k.c0, c1 = k.c1, s0 = k.s0, s1 = k.s1;
-        if (C + 1 < 16) fetch<(C + 1) & 15>(acc, stage, f_wave, n_wave, lane, F, N, k);
+        const int fc = min(f, F - 8), d = f & (HDP - 1);
+        const float4 b0 = *reinterpret_cast<const float4 *>(bias + fc), b1 = *reinterpret_cast<const float4 *>(bias + fc + 4);
+        float v[8] = {k.lo.x + b0.x, k.lo.y + b0.y, k.lo.z + b0.z, k.lo.w + b0.w, k.hi.x + b1.x, k.hi.y + b1.y, k.hi.z + b1.z, k.hi.w + b1.w};
+        const float4 c0 = k.c0, c1 = k.c1;
         if (sec < 2) {
+            const float *sc = (sec == 1 ? ks : qs) + d;
+            const float4 s0 = *reinterpret_cast<const float4 *>(sc), s1 = *reinterpret_cast<const float4 *>(sc + 4);
             const float post = sec == 0 ? q_premul : 1.0f;
             float ss = 0.0f;
 #pragma unroll
@@ -403,6 +398,9 @@ struct EpiLinear1 {
 #pragma unroll
             for (int e = 4; e < 8; ++e) v[e] = gelu_fast(v[e]);
         }
+        // the next piece's rows / tables are requested once this piece's arithmetic no longer needs the current ones (no copies
+        // of the pipe registers); they have the rest of the interval to arrive
+        if (C + 1 < 4 * MI) fetch<(C + 1) % (4 * MI)>(acc, stage, f_wave, n_wave, lane, F, N, k);
         if (f_ok && n < N && !(probe & 16)) {
             const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
             u16 *dst = sec_out < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
@@ -469,9 +467,10 @@ struct EpiLinear2 {
     };
     static constexpr int pieces = 16;
     static constexpr size_t pp_stage_bytes = 4096;
+    static constexpr int piece_ops(bool last) { return last ? 2 : 6; }  // next piece's gate + h rows 4 loads, 2 stores
 
-    template <int C>
-    __device__ __forceinline__ void fetch(f32x16 (&acc)[4][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
+    template <int C, int MI>
+    __device__ __forceinline__ void fetch(f32x16 (&acc)[MI][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
         constexpr int i = C >> 2, j = (C >> 1) & 1, hb = C & 1;
         const int r = lane & 31, hf = lane >> 5, chunk = lane & 7;
         const int f = f_wave + i * 32 + 4 * chunk;
@@ -495,8 +494,8 @@ struct EpiLinear2 {
         for (int it = 0; it < 2; ++it) k.a[it] = *reinterpret_cast<const float4 *>(stage + swz_bk<64>(16 * hb + 8 * it + (lane >> 3), chunk));
     }
 
-    template <int C>
-    __device__ __forceinline__ void piece(f32x16 (&acc)[4][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
+    template <int C, int MI>
+    __device__ __forceinline__ void piece(f32x16 (&acc)[MI][2], char *stage, int f_wave, int n_wave, int lane, int F, int N, Pipe &k) const {
         constexpr int i = C >> 2, j = (C >> 1) & 1, hb = C & 1;
         const int chunk = lane & 7;
         const int f = f_wave + i * 32 + 4 * chunk;
@@ -508,7 +507,7 @@ struct EpiLinear2 {
             out[it].z = fmaf(k.gt[it].z, k.a[it].z + k.b.z, k.hv[it].z);
             out[it].w = fmaf(k.gt[it].w, k.a[it].w + k.b.w, k.hv[it].w);
         }
-        if (C + 1 < 16) fetch<(C + 1) & 15>(acc, stage, f_wave, n_wave, lane, F, N, k);
+        if (C + 1 < 4 * MI) fetch<(C + 1) % (4 * MI)>(acc, stage, f_wave, n_wave, lane, F, N, k);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int n = n_wave + j * 32 + 16 * hb + 8 * it + (lane >> 3);

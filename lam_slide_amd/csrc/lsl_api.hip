@@ -16,6 +16,7 @@
 
 #include "k_attn.cuh"
 #include "k_gemm_pp.cuh"
+#include "k_gemm_drain.cuh"
 #include "k_small.cuh"
 
 namespace {
@@ -239,6 +240,22 @@ void launch_gemm_pp_t(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g, epi);
 }
 
+// epilogue of tile i inside the main loop of tile i+1 (k_gemm_drain.cuh); false when the shape is outside what it covers
+template <class Epi>
+bool launch_gemm_drain(const GemmArgs &g, const Epi &epi, hipStream_t st) {
+    if (g.F % 256 != 0 || g.N % 128 != 0 || g.K % 64 != 0 || g.K / 64 < 2) return false;
+    auto kern = k_gemm_drain<Epi>;
+    constexpr size_t lds = GemmDrainCfg<Epi>::lds_bytes;
+    static bool once = (allow_lds(kern, lds), true);
+    (void)once;
+    const int tiles = (g.N / 128) * (g.F / 256);
+    int grid = device_cus();
+    grid -= grid % 8;
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g, epi);
+    return true;
+}
+
 // ping-pong halves (k_gemm_pp.cuh); false when the shape is outside what the schedule covers
 template <int BK, int NS, class Epi>
 bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
@@ -282,6 +299,7 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     Epi epi = epi_in;
     epi.probe = probe | ((nt >> (std::is_same<Epi, EpiLinear2>::value ? 1 : 0)) & 1 ? 32 : 0);
     const bool pp_ok = !std::is_same<Epi, EpiLinear2>::value ? hhd % 32 == 0 : true;  // linear1 sections start on 32-feature tiles
+    if (variant == 30 && launch_gemm_drain(g, epi, st)) return;
     if (variant == 20 && pp_ok && launch_gemm_pp<32, 4>(g, epi, st)) return;
     if (variant == 21 && pp_ok && launch_gemm_pp<64, 2>(g, epi, st)) return;
     if (variant == 22 && pp_ok && launch_gemm_pp<64, 3>(g, epi, st)) return;
