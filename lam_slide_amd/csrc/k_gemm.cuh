@@ -49,10 +49,14 @@ struct GemmCfg {
     static constexpr int WF = BF / NWF, WT = BT / NWT;
     static constexpr size_t ring_bytes = (size_t)NS * (BF + BT) * BK * 2;
     static constexpr size_t stage_bytes = (size_t)NW * Epi::template wave_stage_bytes<WF, WT>();
-    // PERSIST: the output staging sits BEHIND the ring, so the next tile's first k-tiles stream into the ring
-    // while the epilogue of the current tile drains through the staging area; otherwise staging overlays the ring
-    static constexpr size_t stage_base = PERSIST ? ring_bytes : 0;
-    static constexpr size_t lds_bytes = PERSIST ? ring_bytes + stage_bytes : (ring_bytes > stage_bytes ? ring_bytes : stage_bytes);
+    // PERSIST: the next tile's first k-tiles stream into the ring while the epilogue of the current tile drains through the
+    // staging area, so the two must not overlap: the staging sits BEHIND the ring - or, with a two-slot ring and an even number
+    // of k-tiles (host check), in slot 1: the last k-tile of a tile lives there and is dead once the main loop has finished,
+    // while the prefetch of the next tile's k-tile 0 goes to slot 0.  Not PERSIST: staging overlays the ring.
+    static constexpr bool stage_in_slot1 = PERSIST && NS == 2 && stage_bytes <= ring_bytes / 2;
+    static constexpr size_t stage_base = !PERSIST ? 0 : stage_in_slot1 ? ring_bytes / 2 : ring_bytes;
+    static constexpr size_t lds_bytes =
+        !PERSIST ? (ring_bytes > stage_bytes ? ring_bytes : stage_bytes) : stage_in_slot1 ? ring_bytes : ring_bytes + stage_bytes;
     static_assert(lds_bytes <= 163840, "LDS budget (160 KiB per workgroup)");
 };
 
@@ -138,6 +142,7 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
     }
     set_tile(blockIdx.x);
     prologue();
+    bool prev_full = false;  // the tile whose epilogue ran last was a full one (all its stores were issued)
     for (int v = blockIdx.x; v < ntiles; v += PERSIST ? gridDim.x : ntiles) {
     const bool first_tile = v == (int)blockIdx.x;
     f32x16 acc[MI][NJ];
@@ -153,6 +158,10 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
         // On later tiles the previous epilogue's stores are younger than this tile's first k-tiles in the vmcnt
         // queue, so the first wait drains everything (the k-tiles were issued a whole epilogue ago).
         const int ahead = (kt == 0 && !first_tile) ? 0 : min(nk - 1 - kt, NS - 2);
+        if (PERSIST && kt == 0 && !first_tile && prev_full) {  // the previous tile's last stores may stay in flight
+            constexpr int LB = Epi::template min_store_ops<MI, NJ>() < 48 ? Epi::template min_store_ops<MI, NJ>() : 48;
+            wait_vmcnt<LB>();
+        } else
         switch (ahead) {
             case 0: wait_vmcnt<0>(); break;
             case 1: wait_vmcnt<LPS>(); break;
@@ -200,6 +209,7 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
 
     __syncthreads();  // every wave is done with the operand ring
     const int fw = f_base + wf * WF, nw = n_base + wt * WT;
+    prev_full = f_base + BF <= g.F && n_base + BT <= g.N && !(g.probe & 4);
     if (PERSIST && v + (int)gridDim.x < ntiles) {  // stream the next tile's first k-tiles while this tile's epilogue runs
         set_tile(v + gridDim.x);
         prologue();
@@ -238,6 +248,10 @@ struct EpiLinear1 {
 
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return (size_t)64 * 32 * 4; }
+    // global stores a wave issues for a FULL tile (a lower bound of its vector-memory instructions in the epilogue): what a counted
+    // s_waitcnt may leave in flight when a persistent workgroup only needs the LDS-DMA loads it issued BEFORE the epilogue
+    template <int MI, int NJ>
+    static constexpr int min_store_ops() { return MI * NJ * 2; }
 
     template <int MI, int NJ>
     __device__ __forceinline__ void run(f32x16 (&acc)[MI][NJ], char *stage, int f_wave, int n_wave, int lane, int F, int N) const {
@@ -420,6 +434,8 @@ struct EpiLinear2 {
 
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return (size_t)32 * WT * 4; }  // one 32-feature slab of the wave tile
+    template <int MI, int NJ>
+    static constexpr int min_store_ops() { return MI * NJ * 4; }
 
     template <int MI, int NJ>
     __device__ __forceinline__ void run(f32x16 (&acc)[MI][NJ], char *stage, int f_wave, int n_wave, int lane, int F, int N) const {
@@ -527,6 +543,8 @@ struct EpiPieces : E {
 
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return E::pp_stage_bytes; }
+    template <int MI, int NJ>
+    static constexpr int min_store_ops() { return 16 * (E::piece_ops(true) == 2 ? 2 : 1); }  // 16 pieces, 1 (linear1) or 2 (linear2) stores each
 
     template <int MI, int NJ>
     __device__ __forceinline__ void run(f32x16 (&acc)[MI][NJ], char *stage, int f_wave, int n_wave, int lane, int F, int N) const {

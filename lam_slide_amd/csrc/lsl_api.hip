@@ -276,10 +276,11 @@ bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 //   7  256x256  8 waves 64x2, persistent, piece-form epilogue (4 KiB staging per wave, next piece prefetched): linear2 default
 //   8  256x256  8 waves 32x3, persistent, piece-form epilogue
 //   11 128x128  4 waves 64x2
+//   12 256x256  8 waves 64x2, persistent, two-phase epilogue staged in ring slot 1 (needs an even number of k-tiles)
 //   13 256x128  4 waves 32x2, persistent, two workgroups per CU
 //   15 256x256 16 waves 64x2 (64x64 per wave, 4 waves/SIMD: the light linear2 epilogue fits the 128-VGPR budget and the
 //      extra occupancy hides load / store latency)
-// 20-22: ping-pong halves (k_gemm_pp.cuh).  Default (-1): 5 for linear1 (6 when K is not a multiple of 64), 7 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
+// 20-22: ping-pong halves (k_gemm_pp.cuh).  Default (-1): 12 for linear1 (5 when K < 512 or not a multiple of 128, 6 when not a multiple of 64), 7 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
 // every variant that was tried, including the ones no longer compiled in).
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi_in, hipStream_t st, int hhd = 32) {
@@ -290,7 +291,7 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
     const int ragged_variant = std::is_same<Epi, EpiLinear2>::value && K % 64 == 0 ? 11 : 10;  // measured on the D = 384 / 128 models
-    const int variant = forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 64 == 0 ? 7 : 15) : (K % 64 == 0 ? 5 : 6));
+    const int variant = forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 && K >= 512 ? 12 : K % 64 == 0 ? 5 : 6));
     static const int probe = env_int("LSL_PROBE", 0);
     static const int stagger = env_int("LSL_STAGGER", 0);
     GemmArgs g{W, X, F, N, K, stagger, probe};
@@ -303,7 +304,8 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     if (variant == 20 && pp_ok && launch_gemm_pp<32, 4>(g, epi, st)) return;
     if (variant == 21 && pp_ok && launch_gemm_pp<64, 2>(g, epi, st)) return;
     if (variant == 22 && pp_ok && launch_gemm_pp<64, 3>(g, epi, st)) return;
-    if (variant == 7 && F % 32 == 0 && pp_ok) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, EpiPieces<Epi>(epi), st);  // persistent, 64-deep k-tiles, piece epilogue
+    if (variant == 12 && K % 128 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, epi, st);  // 5 made persistent (staging in ring slot 1)
+    if (variant == 7 && F % 32 == 0 && pp_ok && K % 128 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, EpiPieces<Epi>(epi), st);  // persistent, 64-deep k-tiles, piece epilogue
     if (variant == 8 && F % 32 == 0 && pp_ok) return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, EpiPieces<Epi>(epi), st);  // variant 6 with the piece epilogue
     switch (variant) {
         case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
