@@ -435,3 +435,43 @@ def test_forward_edge_shapes_vs_oracle(name, dev):
     print(f"{name}: rel L2 {err:.3e}")
     assert net.last_path == "hip" and torch.isfinite(got).all()
     assert err < 5e-3, (name, err)
+
+
+def test_full_chain_encode_sample_decode_on_device(golden, dev):
+    """Everything SecondStageCondLightningBase.sample does after prepare_inputs (lightning_base.py:217-238 with second_stage/md17.py:
+    115-131), on the device: Stage1Encoder -> setup_conditioning -> fused sampler -> Stage1Decoder, against the same chain on the
+    oracle (each stage of which is pinned to the reference).  Decoded coordinates within the north-star bar."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler, Stage1Decoder, Stage1Encoder
+    from oracle import harness, latent_net, transport as otr
+    e, d = golden("f7_encode.npz"), golden("f6_decode.npz")
+    enc = Stage1Encoder(e.group("p"), num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16)
+    dec = Stage1Decoder(d.group("p"), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+    sh = latent_net.NetShape(depth=2, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2)
+    p = latent_net.random_params(sh, seed=21)
+    net = build_net(sh, p, dev)
+    B, T, A = 2, 6, 21
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B * T, A, 128, generator=g)                       # prepare_inputs output, one row of entities per frame
+    ent = torch.stack([torch.randperm(32, generator=g)[:A] for _ in range(B * T)])
+    mask = torch.ones(B * T, A, dtype=torch.bool)
+    mask[:, 18:] = False
+    init = torch.randn(B, T, 48, 32, generator=g)
+    skw = {"sampling_method": "euler", "num_steps": 6}
+
+    def encode(batch):
+        z = enc.encode(batch["x"].to(dev), batch["entities"].to(dev), batch["mask"].to(dev))
+        return z.reshape(B, T, *z.shape[1:])
+
+    drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, 2), mask_cond_mean=True, sampling_kwargs=skw,
+                             encode=encode, decode=dec)
+    lat = drv.encode({"x": x, "entities": ent, "mask": mask})
+    final = drv.sample_latents(lat, init=init.to(dev))
+    pos = dec.decode(final.reshape(B * T, 48, 32), ent.to(dev)).cpu()
+
+    lat_o = harness.encode(e.group("p"), harness.EncoderShape(num_latents=48), x, ent, mask).reshape(B, T, 48, 32)
+    xc, m = harness.setup_conditioning(lat_o, (0, 2), True)
+    final_o = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, m, None, "ODE", skw)
+    pos_o = harness.decode(d.group("p"), harness.DecoderShape(), final_o.reshape(B * T, 48, 32), ent)
+    err_lat, err_pos = rel_l2(final.cpu(), final_o), rel_l2(pos, pos_o)
+    print(f"full chain: encoded latents {rel_l2(lat.cpu(), lat_o):.2e}, sampled latents {err_lat:.2e}, decoded coordinates {err_pos:.2e}")
+    assert err_pos < 1e-3 and err_lat < 3e-3
