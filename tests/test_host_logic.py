@@ -277,3 +277,35 @@ def test_sample_rollout_chains_on_last_frame():
     assert torch.equal(seen[0], norm) and torch.equal(seen[1], norm + 3) and torch.equal(seen[2], norm + 6)
     assert torch.equal(out[0], cond)                                # frame 0 = the conditioning frame
     assert torch.equal(out[4], (norm + 3 + 2) * 2.0 + 10.0)        # rollout 1, frame 1
+
+
+def test_stage1_encoder_packing_on_cpu(golden):
+    """Host logic of the encoder wrapper: shapes read off the reference-named state dict, loud failure without a GPU, mismatching
+    head arguments rejected."""
+    from lam_slide_amd import Stage1Encoder
+    d = golden("f7_encode.npz")
+    p = d.group("p")
+    enc = Stage1Encoder(p, num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16)
+    assert (enc.dim_input, enc.dim_emb, enc.n_entities, enc.dim_latent, enc.num_latents) == (128, 128, 32, 32, 48)
+    assert (enc.num_block_cross, enc.num_block_attn, enc.qk_norm) == (1, 1, True)
+    with pytest.raises(RuntimeError):
+        enc.encode(d["x"], d["entities"], d["mask"])
+    with pytest.raises(ValueError):
+        Stage1Encoder(p, num_head_cross=4, dim_head_cross=16, num_head_latent=2, dim_head_latent=16)
+    with pytest.raises(KeyError):
+        Stage1Encoder({k: v for k, v in p.items() if k != "encoder.latents"}, num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16)
+
+
+def test_decoder_query_splitter_rows_reordered(golden):
+    """The 1x1-conv extender of DecoderQuerySplitter as a Linear whose output IS the (latent, split) token sequence: row n*D + d of the
+    packed weight = conv channel d*N + n (decoder.py:384-388 'B (D N) L -> B (L N) D')."""
+    from lam_slide_amd import Stage1Decoder
+    d = golden("f8_decode_split.npz")
+    p = d.group("p")
+    dec = Stage1Decoder(p, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16, act="gelu_tanh")
+    w, b = p["decoder.extender.1.weight"][..., 0], p["decoder.extender.1.bias"]
+    D, N = dec.dim_latent, dec.num_split
+    lat = torch.randn(3, 5, D, generator=torch.Generator().manual_seed(1))
+    ref = torch.nn.functional.linear(lat, w, b).reshape(3, 5, D, N).permute(0, 1, 3, 2).reshape(3, 5 * N, D)
+    mine = torch.nn.functional.linear(lat, dec._sd["decoder.extender.rows"], dec._sd["decoder.extender.rows_bias"]).reshape(3, 5 * N, D)
+    assert N == 4 and torch.equal(ref, mine)
