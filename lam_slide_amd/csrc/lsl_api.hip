@@ -65,6 +65,10 @@ struct lsl_model {
     bool has_weights = false;
     int chunk = 0;
     int HHD, F1, K2, MODW;
+    // second lane of lsl_sample (LSL_LANES=2): passes alternate between the caller's stream and this one, so that the memory-bound
+    // kernels of one pass can share the chip with the GEMMs of the other (created on first use, fork / join by events)
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t lane_fork = nullptr, lane_join = nullptr;
 };
 
 namespace {
@@ -104,6 +108,12 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     return ws;
 }
 
+int env_int(const char *name, int dflt);
+int n_lanes() {
+    static const int l = env_int("LSL_LANES", 1);
+    return l >= 2 ? 2 : 1;
+}
+
 int default_chunk(const lsl_model *m, int B, int T, int L) {
     if (m->chunk > 0) return m->chunk < B ? m->chunk : B;
     if (const char *e = getenv("LSL_CHUNK_TRAJ")) {
@@ -115,7 +125,9 @@ int default_chunk(const lsl_model *m, int B, int T, int L) {
     // workspace stays at a few GiB (of 288).
     size_t c = (size_t)262144 / ((size_t)T * L ? (size_t)T * L : 1);
     if (c < 1) c = 1;
-    return (int)(c < (size_t)B ? c : (size_t)B);
+    if (c > (size_t)B) c = B;
+    if (n_lanes() == 2 && B > 1 && c > (size_t)(B + 1) / 2) c = (B + 1) / 2;  // at least one pass per lane
+    return (int)c;
 }
 
 template <typename K>
@@ -520,7 +532,7 @@ int check_call(const lsl_model *m, const lsl_io *io, size_t ws_bytes, void *ws, 
     if ((io->y != nullptr) != (m->d.vec_in_dim > 0) && io->y != nullptr) return fail(-3, "y given but the model has no vec_in");
     if ((size_t)io->T * io->L > (1u << 24)) return fail(-3, "T*L too large");
     const int chunk = default_chunk(m, io->B, io->T, io->L);
-    const size_t need = carve(m, nullptr, chunk, io->T, io->L).bytes;
+    const size_t need = carve(m, nullptr, chunk, io->T, io->L).bytes * n_lanes();
     if (!ws || ws_bytes < need) return fail(-4, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
     *chunk_out = chunk;
     return 0;
@@ -578,7 +590,12 @@ int lsl_model_set_weights(lsl_model *m, const lsl_weights *w) {
 }
 
 void lsl_model_destroy(lsl_model *m) {
-    if (m) m->prof.clear();
+    if (m) {
+        m->prof.clear();
+        if (m->lane_fork) hipEventDestroy(m->lane_fork);
+        if (m->lane_join) hipEventDestroy(m->lane_join);
+        if (m->lane_stream) hipStreamDestroy(m->lane_stream);
+    }
     delete m;
 }
 
@@ -622,7 +639,7 @@ int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
 
 size_t lsl_workspace_bytes(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
     if (!m || B <= 0 || T <= 0 || L <= 0) return 0;
-    return carve(m, nullptr, default_chunk(m, B, T, L), T, L).bytes;
+    return carve(m, nullptr, default_chunk(m, B, T, L), T, L).bytes * n_lanes();
 }
 
 int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspace_bytes, void *stream) {
@@ -653,23 +670,58 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
         for (int s = n_noise < 0 ? 0 : n_noise; s < n_steps; ++s)
             if (steps[s].aw != 0.0f) return fail(-3, "step %d needs noise but only %d slices were given", s, n_noise);
     hipStream_t st = (hipStream_t)stream;
-    const Workspace ws = carve(m, (char *)workspace, chunk, io->T, io->L);
-    run_tables(m, ws, io->T, io->L, st);
+    const int lanes = (n_lanes() == 2 && io->B > chunk) ? 2 : 1;
+    hipStream_t lane_st[2] = {st, st};
+    if (lanes == 2) {
+        if (!m->lane_stream) {
+            if (hipStreamCreateWithFlags(&m->lane_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&m->lane_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&m->lane_join, hipEventDisableTiming) != hipSuccess)
+                return fail(-10, "could not create the second lane's stream");
+        }
+        lane_st[1] = m->lane_stream;
+        hipEventRecord(m->lane_fork, st);  // lane 1 starts after everything the caller enqueued before this call
+        hipStreamWaitEvent(m->lane_stream, m->lane_fork, 0);
+    }
+    const size_t ws_lane = carve(m, nullptr, chunk, io->T, io->L).bytes;
+    Workspace wss[2];
+    for (int l = 0; l < lanes; ++l) {
+        wss[l] = carve(m, (char *)workspace + l * ws_lane, chunk, io->T, io->L);
+        run_tables(m, wss[l], io->T, io->L, lane_st[l]);
+    }
     const size_t per = (size_t)io->T * io->L * m->d.in_dim;
     const size_t total = per * io->B;
-    for (int b0 = 0; b0 < io->B; b0 += chunk) {
-        const int bc = io->B - b0 < chunk ? io->B - b0 : chunk;
-        const float *y = io->y ? io->y + (size_t)b0 * m->d.vec_in_dim : nullptr;
-        if (int rc = prepare_pass(m, ws, io->x_cond + b0 * per, io->mask + (size_t)b0 * io->T * io->L, y, bc, io->T, io->L, st)) return rc;
-        for (int s = 0; s < n_steps; ++s) {
-            const lsl_step &sp = steps[s];
-            const float *nz = nullptr;
-            if (sp.aw != 0.0f && noise) nz = noise + (size_t)s * total + b0 * per;
-            float *tr = trace ? trace + (size_t)s * total + b0 * per : nullptr;
-            if (int rc = run_eval(m, ws, io->x + b0 * per, nullptr, nullptr, sp.t, y != nullptr, bc, io->T, io->L, 1, sp.ax, sp.am, sp.aw, nz,
-                                  seed, (unsigned)s, elem_offset + b0 * per, tr, st))
+    // passes in groups of `lanes`; within a group the launches of the lanes are interleaved step by step so that both queues fill together
+    for (int g0 = 0; g0 < io->B; g0 += chunk * lanes) {
+        int b0s[2], bcs[2], nl = 0;
+        for (int l = 0; l < lanes; ++l) {
+            const int b0 = g0 + l * chunk;
+            if (b0 >= io->B) break;
+            b0s[nl] = b0;
+            bcs[nl] = io->B - b0 < chunk ? io->B - b0 : chunk;
+            ++nl;
+        }
+        for (int l = 0; l < nl; ++l) {
+            const float *y = io->y ? io->y + (size_t)b0s[l] * m->d.vec_in_dim : nullptr;
+            if (int rc = prepare_pass(m, wss[l], io->x_cond + b0s[l] * per, io->mask + (size_t)b0s[l] * io->T * io->L, y, bcs[l], io->T, io->L, lane_st[l]))
                 return rc;
         }
+        for (int s = 0; s < n_steps; ++s) {
+            const lsl_step &sp = steps[s];
+            for (int l = 0; l < nl; ++l) {
+                const int b0 = b0s[l];
+                const float *nz = nullptr;
+                if (sp.aw != 0.0f && noise) nz = noise + (size_t)s * total + b0 * per;
+                float *tr = trace ? trace + (size_t)s * total + b0 * per : nullptr;
+                if (int rc = run_eval(m, wss[l], io->x + b0 * per, nullptr, nullptr, sp.t, io->y != nullptr, bcs[l], io->T, io->L, 1, sp.ax, sp.am, sp.aw,
+                                      nz, seed, (unsigned)s, elem_offset + b0 * per, tr, lane_st[l]))
+                    return rc;
+            }
+        }
+    }
+    if (lanes == 2) {  // the caller's stream continues after lane 1 has finished
+        hipEventRecord(m->lane_join, m->lane_stream);
+        hipStreamWaitEvent(st, m->lane_join, 0);
     }
     return 0;
 }
