@@ -33,7 +33,7 @@ __device__ __forceinline__ int k_swz(int row, int chunk) {
 }
 
 template <int HDP, int NW, int ITEMS>
-__global__ void __launch_bounds__(NW * 64) k_attention(AttnArgs a) {
+__global__ void __launch_bounds__(NW * 64, 2) k_attention(AttnArgs a) {  // (min waves/SIMD: MFMA results stay in VGPRs, see k_attention_rows)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = HDP * 2;         // bytes per K/V row
     constexpr int CPR = ROWB / 16;        // 16-byte chunks per row
@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(NW * 64) k_attention(AttnArgs a) {
 // MI355X the online form above spent 17 VALU instructions per score element (profiles/r01_rocprof_summary.txt:
 // VALU : MFMA = 68 : 1), which is what bounds attention at head_dim 32, not the MFMAs.
 template <int HDP, int NW, int ITEMS, int NKT>
-__global__ void __launch_bounds__(NW * 64) k_attention_rows(AttnArgs a) {
+__global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  // >= 4 waves/SIMD: keeps the MFMA results in VGPRs (with the
+    // whole 512-register budget hipcc parks them in AGPRs and spends a v_accvgpr_read per score element to get them back)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = HDP * 2, CPR = ROWB / 16, KS = HDP / 16, WPI = NW / ITEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
