@@ -69,6 +69,18 @@ struct lsl_model {
     // kernels of one pass can share the chip with the GEMMs of the other (created on first use, fork / join by events)
     hipStream_t lane_stream = nullptr;
     hipEvent_t lane_fork = nullptr, lane_join = nullptr;
+    // hipGraph cache of lsl_sample: a call whose arguments (pointers, sizes, step table) repeat is captured once and replayed; the
+    // small-batch configs are launch-bound (~700 launches of a few microseconds per sampling call)
+    struct GraphEntry {
+        std::vector<unsigned char> key;
+        hipGraphExec_t exec = nullptr;
+        unsigned long long last_use = 0;
+    };
+    std::vector<GraphEntry> graphs;
+    std::vector<std::vector<unsigned char>> seen;  // argument sets that ran eagerly once (capture happens on their second appearance)
+    unsigned long long graph_clock = 0;
+    hipStream_t graph_stream = nullptr;  // capture happens on this internal stream (the caller's may be the legacy default stream, which
+                                         // cannot be captured); the instantiated graph is launched on the caller's stream
 };
 
 namespace {
@@ -586,6 +598,10 @@ int lsl_model_set_weights(lsl_model *m, const lsl_weights *w) {
     m->w = *w;
     m->w.blocks = m->blocks.data();
     m->has_weights = true;
+    for (auto &g : m->graphs)  // captured launches hold the old weight pointers
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    m->seen.clear();
     return 0;
 }
 
@@ -595,6 +611,9 @@ void lsl_model_destroy(lsl_model *m) {
         if (m->lane_fork) hipEventDestroy(m->lane_fork);
         if (m->lane_join) hipEventDestroy(m->lane_join);
         if (m->lane_stream) hipStreamDestroy(m->lane_stream);
+        for (auto &g : m->graphs)
+            if (g.exec) hipGraphExecDestroy(g.exec);
+        if (m->graph_stream) hipStreamDestroy(m->graph_stream);
     }
     delete m;
 }
@@ -626,9 +645,17 @@ int lsl_profile_read(lsl_model *m, double *total_ms, int32_t *launches) {
     return 0;
 }
 
+static void drop_graphs(lsl_model *m) {
+    for (auto &g : m->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    m->seen.clear();
+}
+
 int lsl_model_set_chunk(lsl_model *m, int32_t c) {
     if (!m || c < 0) return fail(-1, "bad argument");
     m->chunk = c;
+    drop_graphs(m);
     return 0;
 }
 
@@ -661,6 +688,9 @@ int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspac
     return 0;
 }
 
+static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, uint64_t seed,
+                          uint64_t elem_offset, float *trace, void *workspace, int chunk, hipStream_t st);
+
 int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, int32_t n_noise, uint64_t seed,
                uint64_t elem_offset, float *trace, void *workspace, size_t workspace_bytes, void *stream) {
     int chunk = 0;
@@ -670,6 +700,75 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
         for (int s = n_noise < 0 ? 0 : n_noise; s < n_steps; ++s)
             if (steps[s].aw != 0.0f) return fail(-3, "step %d needs noise but only %d slices were given", s, n_noise);
     hipStream_t st = (hipStream_t)stream;
+    // hipGraph replay (opt-in).  LSL_GRAPH: 0 off (default), 1 for launch-bound calls (at most 64 Ki tokens per pass and 4096 launches) whose
+    // arguments repeat, 2 for every call of at most 4096 launches: the first appearance of an argument set runs eagerly (it also initialises
+    // the per-kernel attributes), the second is captured, later ones are replayed.  Measured on MI355X (tools/latency_small_batch.py): a
+    // 10-update pedestrian call (~600 launches) takes 3.38 ms eagerly and 3.23 ms replayed - the floor of the small-batch configs is the
+    // GPU-side cost of ~600 dependent tiny kernels (5 us each), not the host launches, so replay buys 0-4 % and stays off by default.
+    static const int use_graph = env_int("LSL_GRAPH", 0);
+    const int passes = (io->B + chunk - 1) / chunk;
+    const long est_launches = (long)passes * n_steps * (8L * m->d.depth + 6);
+    const bool launch_bound = (size_t)chunk * io->T * io->L <= 65536;
+    if (use_graph && (launch_bound || use_graph >= 2) && m->prof.kernel < 0 && n_lanes() == 1 && est_launches <= 4096) {
+        std::vector<unsigned char> key;
+        auto put = [&](const void *p, size_t n) { key.insert(key.end(), (const unsigned char *)p, (const unsigned char *)p + n); };
+        put(io, sizeof(*io));
+        put(steps, sizeof(lsl_step) * n_steps);
+        put(&noise, sizeof(noise));
+        put(&seed, sizeof(seed));
+        put(&elem_offset, sizeof(elem_offset));
+        put(&trace, sizeof(trace));
+        put(&workspace, sizeof(workspace));
+        put(&chunk, sizeof(chunk));
+        put(&st, sizeof(st));
+        for (auto &g : m->graphs)
+            if (g.key == key) {
+                g.last_use = ++m->graph_clock;
+                if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail(-10, "hipGraphLaunch failed");
+                return 0;
+            }
+        bool second = false;
+        for (auto &k : m->seen) second |= (k == key);
+        if (second) {
+            hipGraph_t graph = nullptr;
+            if (!m->graph_stream && hipStreamCreateWithFlags(&m->graph_stream, hipStreamNonBlocking) != hipSuccess) m->graph_stream = nullptr;
+            hipStream_t cs = m->graph_stream;
+            if (cs && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = sample_enqueue(m, io, steps, n_steps, noise, seed, elem_offset, trace, workspace, chunk, cs);
+                const hipError_t e = hipStreamEndCapture(cs, &graph);
+                hipGraphExec_t exec = nullptr;
+                if (rc == 0 && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    hipGraphDestroy(graph);
+                    if (m->graphs.size() >= 8) {  // evict the least recently used
+                        size_t lru = 0;
+                        for (size_t i = 1; i < m->graphs.size(); ++i)
+                            if (m->graphs[i].last_use < m->graphs[lru].last_use) lru = i;
+                        hipGraphExecDestroy(m->graphs[lru].exec);
+                        m->graphs.erase(m->graphs.begin() + lru);
+                    }
+                    lsl_model::GraphEntry ge;
+                    ge.key = key;
+                    ge.exec = exec;
+                    ge.last_use = ++m->graph_clock;
+                    m->graphs.push_back(std::move(ge));
+                    if (hipGraphLaunch(exec, st) != hipSuccess) return fail(-10, "hipGraphLaunch failed");
+                    return 0;
+                }
+                if (graph) hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();  // capture not possible: forget the error and run eagerly (this argument set is not tried again)
+            for (auto &k : m->seen)
+                if (k == key) k.clear();
+        } else {
+            if (m->seen.size() >= 16) m->seen.erase(m->seen.begin());
+            m->seen.push_back(key);
+        }
+    }
+    return sample_enqueue(m, io, steps, n_steps, noise, seed, elem_offset, trace, workspace, chunk, st);
+}
+
+static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, uint64_t seed,
+                          uint64_t elem_offset, float *trace, void *workspace, int chunk, hipStream_t st) {
     const int lanes = (n_lanes() == 2 && io->B > chunk) ? 2 : 1;
     hipStream_t lane_st[2] = {st, st};
     if (lanes == 2) {

@@ -181,6 +181,20 @@ class LatentSIV3(nn.Module):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
         return self._workspace
 
+    def pinned(self, tag: str, src: Tensor, dtype: torch.dtype) -> Tensor:
+        """A persistent device buffer per (tag, shape) holding a copy of ``src``: the fused sampler hands the library the SAME pointers on
+        every call of a given shape, which is what lets ``lsl_sample`` replay a captured hipGraph instead of re-launching ~40 kernels
+        per state update (the small-batch configs are launch-bound).  One sampling call at a time per model object."""
+        if not hasattr(self, "_pinned"):
+            self._pinned = {}
+        key = (tag, tuple(src.shape), src.device)
+        buf = self._pinned.get(key)
+        if buf is None:
+            buf = torch.empty(src.shape, dtype=dtype, device=src.device)
+            self._pinned[key] = buf
+        buf.copy_(src)
+        return buf
+
     def __del__(self):
         try:
             if self._handle:

@@ -299,8 +299,14 @@ class Sampler:
         net._require_gpu(init)
         lib = _lib.load()
         net.ensure_packed(init.device)
-        x = init.detach().float().contiguous().clone()
-        io, keep = net.make_io(x, model_kwargs["x_cond"], model_kwargs["x_cond_mask"], model_kwargs.get("y"))
+        # state and conditioning live in per-shape persistent buffers of the model (stable pointers -> hipGraph replay in lsl_sample)
+        x = net.pinned("state", init.detach(), torch.float32)
+        xc = net.pinned("x_cond", model_kwargs["x_cond"].detach(), torch.float32)
+        xm = net.pinned("x_cond_mask", model_kwargs["x_cond_mask"].detach(), torch.int64)
+        yv = model_kwargs.get("y")
+        if yv is not None:
+            yv = net.pinned("y", yv.detach(), torch.float32)
+        io, keep = net.make_io(x, xc, xm, yv)
         ws = net.workspace(io.B, io.T, io.L, init.device)
         arr = (_lib.Step * len(steps))(*[_lib.Step(*s) for s in steps])
         trace = None
@@ -319,7 +325,7 @@ class Sampler:
         net.last_path = "hip"
         self.last_path = "fused"
         del keep
-        x = x.to(init.dtype)
+        x = x.clone() if x.dtype == init.dtype else x.to(init.dtype)  # the persistent buffer is overwritten by the next call
         if trace is None:
             return SampleResult(x, n_result)
         if duplicate_last:  # last_step=None: the reference appends xs[-1] again (transport.py:353-357)

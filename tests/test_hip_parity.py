@@ -475,3 +475,37 @@ def test_full_chain_encode_sample_decode_on_device(golden, dev):
     err_lat, err_pos = rel_l2(final.cpu(), final_o), rel_l2(pos, pos_o)
     print(f"full chain: encoded latents {rel_l2(lat.cpu(), lat_o):.2e}, sampled latents {err_lat:.2e}, decoded coordinates {err_pos:.2e}")
     assert err_pos < 1e-3 and err_lat < 3e-3
+
+
+def test_graph_replay_matches_eager_bits(dev):
+    """LSL_GRAPH=2: repeated sampling calls with the same buffers are captured into a hipGraph on their second appearance and replayed
+    afterwards; results must be the bits of the eager path, also when the INPUT VALUES change between replays (the graph reads through
+    the pointers).  The knob is read once per process, so both arms run in subprocesses."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from lam_slide_amd import CreateTransport, SecondStageSampler\n"
+        "from oracle import latent_net\n"
+        "from test_hip_parity import build_net\n"
+        "dev = torch.device('cuda:0')\n"
+        "sh = latent_net.NetShape(depth=2, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2)\n"
+        "net = build_net(sh, latent_net.random_params(sh, seed=4), dev)\n"
+        "drv = SecondStageSampler(net, CreateTransport('GVP', 'data')(), cond_idx=(0, 3), sampling_kwargs={'sampling_method': 'euler', 'num_steps': 7})\n"
+        "g = torch.Generator().manual_seed(9)\n"
+        "outs = []\n"
+        "for i in range(5):\n"
+        "    lat = torch.randn(3, 10, 6, 32, generator=g).to(dev); init = torch.randn(3, 10, 6, 32, generator=g).to(dev)\n"
+        "    outs.append(drv.sample_latents(lat, init=init).cpu())\n"
+        "torch.save(torch.stack(outs), sys.argv[1])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "2"):
+        path = f"/tmp/lsl_graph_{mode}_{os.getpid()}.pt"
+        env = dict(os.environ, LSL_GRAPH=mode)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+        res[mode] = torch.load(path)
+        os.remove(path)
+    assert torch.equal(res["0"], res["2"])
+    assert not torch.equal(res["0"][0], res["0"][1])
