@@ -6,17 +6,29 @@ each GPU.  Default workload = BASELINE.json configs[1]: MD17 aspirin benchmark s
 tokens, C=32, D=512, H=16, depth 4, mlp_ratio 2, GVP path / data prediction, ODE Euler with 50 state updates
 (reference ``num_steps=51``), bf16 MFMA operands with fp32 accumulate/state.  Inputs are synthetic (seeded
 random weights of that architecture, random conditioning latents) and resident in HBM before the timed
-region.  Multi-GPU: one process per GPU, the batch is sharded (weak scaling: per-GPU batch fixed), no data-path
-collective, one all_gather (RCCL) of the final latents per step inside the timed region.
+region.
+
+Multi-GPU (``--gpus N``): one process per GPU, the batch is sharded (weak scaling: per-GPU batch fixed), no
+data-path collective, one all_gather (RCCL over xGMI, backend "nccl") of the final latents per step inside the
+timed region.  Launched by ``torch.distributed.run`` the ranks are taken from the environment; invoked plainly
+(``python bench.py --gpus 8``) the script starts its N ranks itself as child processes BEFORE any GPU call and
+relays rank 0's single JSON line.  Documented weak-scaling lines beside the headline:
+    python bench.py --gpus N --workload nba --batch 1024        (BASELINE configs[4]: 1024 trajectories per GPU, 8192 at N=8)
+    python bench.py --gpus N --workload peptide --batch 8       (BASELINE configs[3]: 1000-step SDE, 8 trajectories per GPU)
 
 Extra legs on rank 0 at N=1: ``roofline`` (HIP-event timing of the dominant kernel, the linear1 MFMA GEMM,
-inside the timed region) and ``cpu_baseline`` (the CPU oracle restatement timed on the host cores on a
-bounded sample of the same workload).
+inside the timed region), ``gpu_small_batch`` (the same call at B=1 and B=8), ``stage1`` (device encode / decode
+of the batch, the steps either side of the loop) and ``cpu_baseline`` (the CPU oracle restatement timed on the
+host cores: the full solve of one trajectory, which is also this run's parity check, a 1-thread figure and an
+all-core figure with several trajectories in flight).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +43,8 @@ WORKLOADS = {
                  {"sampling_method": "euler", "num_steps": 11}, 4),
     "pedestrian": (dict(depth=6, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2, vec_in_dim=256, normalize=True), 20, 2, (0, 8), "ODE",
                    {"sampling_method": "euler", "num_steps": 11}, 1280),
+    "pedestrian_scene": (dict(depth=6, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2, vec_in_dim=256, normalize=True), 20, 2, (0, 8), "ODE",
+                         {"sampling_method": "euler", "num_steps": 11}, 20),   # BASELINE configs[2] literally: 1 scene x 20 samples
     "nba": (dict(depth=6, in_dim=32, hidden_size=256, num_heads=16, mlp_ratio=4, vec_in_dim=256, normalize=True), 20, 8, (0, 5), "ODE",
             {"sampling_method": "euler", "num_steps": 51}, 1024),
     "peptide": (dict(depth=7, in_dim=96, hidden_size=384, num_heads=16, mlp_ratio=4), 1000, 2, (0, 1), "SDE",
@@ -45,11 +59,7 @@ def flops_per_eval_per_traj(kw, T, L):
     return 6 * n * Cc * D + kw["depth"] * 4 * n * D * (4 * D + 2 * M + L + T)
 
 
-def done_updates(method, n_sample):
-    return n_sample if method == "ODE" else n_sample - 1
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -58,51 +68,155 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU per step (0 = workload default)")
     ap.add_argument("--chunk", type=int, default=0, help="trajectories per pass inside the library (0 = default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small-batch and stage-1 legs")
     ap.add_argument("--profile-kernel", type=int, default=0, help="kernel class timed with HIP events (lsl_api.h)")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed passes: per-kernel-class time shares")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="gloo only with --stub-compute (launcher test on CPU)")
+    ap.add_argument("--stub-compute", action="store_true",
+                    help="launcher / collective plumbing test without a GPU: the sampling call is replaced by a trivial CPU op and the "
+                         "line is marked data=stub (never a measurement)")
+    ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)  # internal: one worker of the all-core CPU leg
+    ap.add_argument("--cpu-threads", type=int, default=1, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher starts the N ranks itself (no GPU call happens in this parent)
+
+
+def launch_ranks(args) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if any(rcs) or not lines:
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n{out0 or ''}\n")
+        return next((rc for rc in rcs if rc), 1)
+    print(lines[-1])
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline helpers (the oracle is the checker; here it is timed, never shipped)
+
+
+def cpu_oracle_runner(workload, inputs=None):
+    """n -> final latents after n state updates of ONE trajectory on the CPU oracle.  inputs = (init, x_cond, mask, y) of that trajectory
+    (the parity leg hands over the tensors of the GPU run); None: seeded stand-ins of the same shape (timing-only workers)."""
+    import torch as th
+    from lam_slide_amd import LatentSIV3, setup_conditioning
+    from lam_slide_amd.synthetic import seeded_state_dict
+    from oracle import harness, latent_net, transport as otr
+    kw, T, L, cond_idx, method, skw, _ = WORKLOADS[workload]
+    params = seeded_state_dict(LatentSIV3(reset_parameters=False, **kw), seed=0)
+    sh = latent_net.NetShape(**kw)
+    if inputs is None:
+        g = th.Generator().manual_seed(1)
+        lat = th.randn(1, T, L, kw["in_dim"], generator=g)
+        init = th.randn(1, T, L, kw["in_dim"], generator=g)
+        y = th.randn(1, kw["vec_in_dim"], generator=g) if kw.get("vec_in_dim") else None
+        xc, m = setup_conditioning(lat, cond_idx, True)
+    else:
+        init, xc, m, y = inputs
+    tr = otr.Transport("GVP", "data")
+    if method == "ODE":
+        return lambda n: harness.sample_latents(params, sh, tr, init, xc, m, y, "ODE", {"sampling_method": "euler", "num_steps": n + 1})
+    return lambda n: harness.sample_latents(params, sh, tr, init, xc, m, y, "SDE", {"num_steps": n, "last_step": None})
+
+
+def cpu_worker(args) -> int:
+    """One worker of the all-core leg: `--cpu-worker n` runs n state updates of one trajectory with --cpu-threads threads."""
+    import torch as th
+    th.set_num_threads(args.cpu_threads)
+    run = cpu_oracle_runner(args.workload)
+    one = 1 if WORKLOADS[args.workload][4] == "ODE" else 2
+    run(one)
+    t0 = time.perf_counter()
+    run(args.cpu_worker)
+    print(json.dumps({"seconds": time.perf_counter() - t0, "updates": args.cpu_worker if one == 1 else args.cpu_worker - 1}))
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+
+
+def run_rank(args) -> int:
     import torch
     import torch.distributed as dist
-    from lam_slide_amd import CreateTransport, LatentSIV3, Sampler, _lib, setup_conditioning
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    stub = args.stub_compute
+    if args.backend == "gloo" and not stub:
+        raise SystemExit("--backend gloo is only for --stub-compute (the product path has no CPU implementation)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback of the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if stub:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     kw, T, L, cond_idx, method, skw, default_b = WORKLOADS[args.workload]
     B = args.batch or default_b
-    from lam_slide_amd.synthetic import seeded_state_dict
-    net = LatentSIV3(reset_parameters=False, **kw)
-    params = seeded_state_dict(net, seed=0)
-    net.load_state_dict(params)
-    net.to(dev)
-    if args.chunk:
-        net.set_chunk(args.chunk)
-    tr = CreateTransport("GVP", "data")()
-
+    n_evals = (skw["num_steps"] - 1) if method == "ODE" else skw["num_steps"]
     g = torch.Generator().manual_seed(1 + rank)
-    lat = torch.randn(B, T, L, kw["in_dim"], generator=g).to(dev)
-    init = torch.randn(B, T, L, kw["in_dim"], generator=g).to(dev)
-    y = torch.randn(B, kw["vec_in_dim"], generator=g).to(dev) if kw.get("vec_in_dim") else None
-    x_cond, mask = setup_conditioning(lat, cond_idx, True)
-    mk = {"x_cond": x_cond, "x_cond_mask": mask}
-    if y is not None:
-        mk["y"] = y
-    sampler = Sampler(tr, fused=True, seed=1234)
-    sampler.elem_offset = rank * B * T * L * kw["in_dim"]
-    fn = sampler.get_sample_fn(method, skw)
+
+    if stub:
+        dev = torch.device("cpu")
+        init = torch.randn(B, 4, 4, kw["in_dim"], generator=g)
+
+        def sample_call():
+            return init * 0.5
+
+        def sync():
+            pass
+    else:
+        from lam_slide_amd import CreateTransport, LatentSIV3, Sampler, _lib, setup_conditioning
+        from lam_slide_amd.synthetic import seeded_state_dict
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback of the product path)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        net = LatentSIV3(reset_parameters=False, **kw)
+        params = seeded_state_dict(net, seed=0)
+        net.load_state_dict(params)
+        net.to(dev)
+        if args.chunk:
+            net.set_chunk(args.chunk)
+        tr = CreateTransport("GVP", "data")()
+        lat = torch.randn(B, T, L, kw["in_dim"], generator=g).to(dev)
+        init = torch.randn(B, T, L, kw["in_dim"], generator=g).to(dev)
+        y = torch.randn(B, kw["vec_in_dim"], generator=g).to(dev) if kw.get("vec_in_dim") else None
+        x_cond, mask = setup_conditioning(lat, cond_idx, True)
+        mk = {"x_cond": x_cond, "x_cond_mask": mask}
+        if y is not None:
+            mk["y"] = y
+        sampler = Sampler(tr, fused=True, seed=1234)
+        sampler.elem_offset = rank * B * T * L * kw["in_dim"]
+        fn = sampler.get_sample_fn(method, skw)
+        net.ensure_packed(dev)
+        lib = _lib.load()
+
+        def sample_call():
+            return fn(init, net.forward, **mk)[-1]
+
+        def sync():
+            torch.cuda.synchronize()
+
     gather = [torch.empty_like(init) for _ in range(world)] if world > 1 else None
 
     def one_step():
-        final = fn(init, net.forward, **mk)[-1]
+        final = sample_call()
         if world > 1:
             dist.all_gather(gather, final.contiguous())
         return final
@@ -110,14 +224,11 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    net.ensure_packed(dev)
     for _ in range(args.warmup):
         one_step()
-    lib = _lib.load()
-    n_evals = (skw["num_steps"] - 1) if method == "ODE" else skw["num_steps"]
-    if rank == 0:
+    if rank == 0 and not stub:
         _lib.check(lib.lsl_profile_enable(net._handle, args.profile_kernel, 4096))
     fence()
     t0 = time.perf_counter()
@@ -125,26 +236,55 @@ def main():
         final = one_step()
     fence()
     dt = time.perf_counter() - t0
+    gather_ms = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    assert os.environ.get("LSL_PROBE") or torch.isfinite(final).all()
+        # the one collective of the path, timed on its own (outside the timed region above): RCCL all_gather of the final latents
+        fence()
+        tg = time.perf_counter()
+        for _ in range(5):
+            dist.all_gather(gather, final.contiguous())
+        fence()
+        gather_ms = (time.perf_counter() - tg) / 5 * 1e3
+    assert torch.isfinite(final).all()
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        return 0
+
+    traj = B * world * args.steps
+    value = traj / dt
+    D, M = kw["hidden_size"], int(kw["hidden_size"] * kw["mlp_ratio"])
+    out = {
+        "metric": "sampled trajectories/sec (50-step ODE) + decoded-coord L2 vs ref, MD17" if args.workload == "md17_bench"
+        else f"sampled trajectories/sec ({args.workload})",
+        "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "dtype_detail": "bf16 MFMA operands (linear1, linear2, attention), fp32 accumulators / residual state / small GEMMs",
+        "data": "stub (launcher test, not a measurement)" if stub else "synthetic (seeded random weights and latents)",
+        "config": {"workload": args.workload, "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
+                   "mlp_ratio": kw["mlp_ratio"], "sampler": method, "state_updates": n_evals, "batch_per_gpu": B,
+                   "global_batch": B * world, "parallelism": f"batch-shard x{world}, 1 all_gather/step"},
+        "rccl_ranks": rccl_ranks, "collective_backend": args.backend if world > 1 else None, "gather_ms": gather_ms,
+    }
+    if stub:
+        out.update({"roofline": None, "cpu_baseline": None})
+        print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
 
     total_ms, launches = C.c_double(), C.c_int32()
     _lib.check(lib.lsl_profile_read(net._handle, C.byref(total_ms), C.byref(launches)))
     lib.lsl_profile_enable(net._handle, -1, 0)
-    traj = B * world * args.steps
-    value = traj / dt
     f_eval = flops_per_eval_per_traj(kw, T, L)
-    D, M = kw["hidden_size"], int(kw["hidden_size"] * kw["mlp_ratio"])
     ws_bytes = lib.lsl_workspace_bytes(net._handle, B, T, L)
     pass_size = lib.lsl_pass_size(net._handle, B, T, L)
+    out["config"].update({"trajectories_per_pass": pass_size, "workspace_mib": round(ws_bytes / 2 ** 20, 1)})
     passes = -(-B // pass_size)
     block_evals = 2 * kw["depth"] * n_evals * args.steps          # launches of each block kernel per pass
     launches_total = passes * block_evals
@@ -155,20 +295,22 @@ def main():
         2: ("k_attention", 4.0 * tok_total * D * (L + T) / 2 * block_evals),
     }.get(args.profile_kernel, (f"kernel class {args.profile_kernel}", 0.0))
     avg_ms = total_ms.value / max(1, launches.value)
-    flops_per_launch = kflops_total / launches_total            # algorithmic FLOPs of one launch
+    flops_per_launch = kflops_total / max(1, launches_total)      # algorithmic FLOPs of one launch
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 and kflops_total else None
-    # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see profiles/): measured
-    # on a 61 440-token launch of this workload; both operand and output bytes scale with the tokens of a launch (weights
-    # are < 1 % of them), so the per-token figure is scaled to this run's tokens per launch.
+    # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see profiles/): both operand and
+    # output bytes scale with the tokens of a launch (weights are < 1 % of them), so the per-token figure is scaled to this run's
+    # tokens per launch.  The newest profiles/r*_traffic.json of this workload is used.
     traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        key = {0: "linear1", 1: "linear2"}.get(args.profile_kernel)
-        if key and tj["workload"] == args.workload:
-            traffic = int(tj[key]["bytes"] / tj["tokens_per_launch"] * min(pass_size, B) * T * L)
-    except (OSError, KeyError, ValueError):
-        pass
-    roofline = {
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(tf))
+            key = {0: "linear1", 1: "linear2"}.get(args.profile_kernel)
+            if key and tj["workload"] == args.workload:
+                traffic = int(tj[key]["bytes"] / tj["tokens_per_launch"] * min(pass_size, B) * T * L)
+                break
+        except (OSError, KeyError, ValueError):
+            continue
+    out["roofline"] = {
         "bound": "mfma", "kernel": kname, "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
         "frac": (achieved / PEAK_BF16_DENSE_TFLOPS) if achieved else None, "traffic": traffic,
         "launches_timed": launches.value, "launches_total": launches_total, "avg_launch_ms": avg_ms,
@@ -178,7 +320,15 @@ def main():
         "whole_path_frac": value * f_eval * n_evals / 1e12 / PEAK_BF16_DENSE_TFLOPS,
     }
 
-    breakdown = None
+    def timed_call(fn_, reps=1):
+        fn_()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            fn_()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / reps
+
     if args.breakdown:
         breakdown = {}
         names = ["linear1", "linear2", "attention", "ln_modulate", "head_step", "embed", "modulation"]
@@ -192,86 +342,134 @@ def main():
             _lib.check(lib.lsl_profile_read(net._handle, C.byref(total_ms), C.byref(launches)))
             breakdown[nm] = {"ms": round(total_ms.value, 3), "launches": launches.value, "share_of_step": round(total_ms.value * 1e-3 / wall, 4)}
         lib.lsl_profile_enable(net._handle, -1, 0)
-
-    cpu = None
-    if not args.no_cpu and world == 1:
-        from oracle import harness, latent_net, transport as otr  # the checker, timed as the CPU baseline only
-        import torch as th
-        sh = latent_net.NetShape(**kw)
-        host_cores = os.cpu_count() or 1
-        xc_c, m_c = x_cond[:1].cpu(), mask[:1].cpu()
-        y_c = y[:1].cpu() if y is not None else None
-        x_c = init[:1].cpu()
-        n_sample = max(2, min(n_evals, 5))
-        otr_t = otr.Transport("GVP", "data")
-        if method == "ODE":
-            run = lambda n: harness.sample_latents(params, sh, otr_t, x_c, xc_c, m_c, y_c, "ODE", {"sampling_method": "euler", "num_steps": n + 1})  # noqa: E731
-        else:  # the reference evaluates the network twice per SDE step (drift and score)
-            run = lambda n: harness.sample_latents(params, sh, otr_t, x_c, xc_c, m_c, y_c, "SDE", {"num_steps": n, "last_step": None})  # noqa: E731
-        # Thread count: all cores is far from best for these small fp32 ops (256 threads measured 57 s per update on the
-        # GPU box); calibrate on one update per candidate, then time the sample with the fastest and report it as `cores`.
-        one = 1 if method == "ODE" else 2
-        best, cal = None, {}
-        for c in [c for c in (8, 16, 32, 64, 128) if c <= host_cores] or [host_cores]:
-            th.set_num_threads(c)
-            if best is None:
-                run(one)  # warm-up (allocator, oneDNN primitives)
-            tc = time.perf_counter()
-            run(one)
-            cal[c] = time.perf_counter() - tc
-            if best is None or cal[c] < cal[best]:
-                best = c
-            if cal[c] > 20.0:
-                break
-        th.set_num_threads(best)
-        n_sample = max(2, min(n_evals, int(round(15.0 * one / cal[best]))))  # about 15 s of CPU work
-        tc = time.perf_counter()
-        cpu_final = run(n_sample)
-        el = time.perf_counter() - tc
-        # parity of THIS workload in the same run: the same n_sample-update solve of trajectory 0 on the HIP path, both decoded to
-        # coordinates (HIP: lsl_decode; CPU: the oracle's decoder restatement) with a seeded frozen decoder of the MD17 shape
-        parity = None
-        if kw["in_dim"] == 32 and method == "ODE":  # (SDE runs draw their noise on different generators on the two sides)
-            from lam_slide_amd import Stage1Decoder
-            from lam_slide_amd.synthetic import seeded_decoder_state_dict
-            skw_n = dict(skw, num_steps=n_sample + 1)
-            mk1 = {k: v[:1] for k, v in mk.items()}
-            hip_final = Sampler(tr, fused=True, seed=1234).get_sample_fn(method, skw_n)(init[:1], net.forward, **mk1)[-1]
-            dsd = seeded_decoder_state_dict(seed=7)
-            dec = Stage1Decoder(dsd, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
-            ent = th.arange(21)[None].expand(T, 21)
-            pos_hip = dec.decode(hip_final[0], ent.to(dev)).cpu()
-            pos_cpu = harness.decode(dsd, harness.DecoderShape(), cpu_final[0], ent)
-            parity = {"latents_rel_l2": harness.rel_l2(hip_final.cpu(), cpu_final), "decoded_coord_rel_l2": harness.rel_l2(pos_hip, pos_cpu),
-                      "what": f"trajectory 0, {done_updates(method, n_sample)} state updates, HIP sampler + HIP decode vs CPU oracle sampler + oracle decode"}
-        done = n_sample if method == "ODE" else n_sample - 1
-        per_update = el / done
-        cpu = {"value": 1.0 / (per_update * n_evals), "unit": "trajectories/s", "cores": best, "kind": "port",
-               "host_cores": host_cores, "calibration_s_per_update": {str(k): round(v, 2) for k, v in cal.items()},
-               "sample": f"oracle restatement (pure PyTorch fp32, reference op structure, {'1' if method == 'ODE' else '2'} network "
-                         f"evaluation(s) per update), B=1, {done} of {n_evals} state updates timed ({el:.1f} s) with {best} threads, "
-                         f"extrapolated linearly to {n_evals}", "parity": parity}
-
-    out = {
-        "metric": "sampled trajectories/sec (50-step ODE) + decoded-coord L2 vs ref, MD17" if args.workload == "md17_bench"
-        else f"sampled trajectories/sec ({args.workload})",
-        "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "dtype_detail": "bf16 MFMA operands (linear1, linear2, attention), fp32 accumulators / residual state / small GEMMs", "data": "synthetic (seeded random weights and latents)",
-        "config": {"workload": args.workload, "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
-                   "mlp_ratio": kw["mlp_ratio"], "sampler": method, "state_updates": n_evals, "batch_per_gpu": B,
-                   "global_batch": B * world, "trajectories_per_pass": pass_size,
-                   "workspace_mib": round(ws_bytes / 2 ** 20, 1), "parallelism": f"batch-shard x{world}, 1 all_gather/step"},
-        "roofline": roofline, "cpu_baseline": cpu,
-    }
-    if cpu:
-        out["speedup_vs_cpu_baseline"] = value / cpu["value"]
-    if breakdown:
         out["breakdown"] = breakdown
+
+    if world == 1 and not args.no_extras:
+        # the same call at small batches (SURVEY 8d asks B = 1 and 8 beside the throughput batch)
+        small = {}
+        for b in (1, 8):
+            if b >= B:
+                continue
+            mkb = {k: v[:b] for k, v in mk.items()}
+            sec = timed_call(lambda: fn(init[:b], net.forward, **mkb)[-1], reps=2)
+            small[f"B{b}"] = {"value": b / sec, "unit": "trajectories/s", "ms_per_call": sec * 1e3}
+        out["gpu_small_batch"] = small
+        # the steps either side of the loop, on the device, for the batch of one step (frozen stage-1 models of the MD17 shape)
+        if kw["in_dim"] == 32:
+            from lam_slide_amd import Stage1Decoder, Stage1Encoder
+            from lam_slide_amd.synthetic import seeded_decoder_state_dict, seeded_encoder_state_dict
+            A = 21
+            enc = Stage1Encoder(seeded_encoder_state_dict(num_latents=L, seed=6), num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16)
+            dec = Stage1Decoder(seeded_decoder_state_dict(seed=7), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+            xin = torch.randn(B * T, A, 128, generator=g).to(dev)
+            ent = torch.arange(A, device=dev)[None].expand(B * T, A).contiguous()
+            em = torch.ones(B * T, A, dtype=torch.bool, device=dev)
+            flat = final.reshape(B * T, L, kw["in_dim"])
+            out["stage1"] = {"frames": B * T, "entities": A,
+                             "encode_ms": timed_call(lambda: enc.encode(xin, ent, em), reps=3) * 1e3,
+                             "decode_ms": timed_call(lambda: dec.decode(flat, ent), reps=3) * 1e3,
+                             "what": "device encode / decode of one step's batch (seeded frozen stage-1 weights), outside the timed region"}
+
+    if not args.no_cpu and world == 1:
+        out["cpu_baseline"] = cpu_leg(args, kw, T, L, method, skw, n_evals, init, mk, net, tr, dev)
+        if out["cpu_baseline"]:
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    else:
+        out["cpu_baseline"] = None
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def cpu_leg(args, kw, T, L, method, skw, n_evals, init, mk, net, tr, dev):
+    """The CPU oracle on the host cores.  `value`: one trajectory (the rank's trajectory 0) solved with the best intra-op thread count -
+    for the headline workload the FULL solve (all 50 updates, no extrapolation), which is also this run's parity check of latents and
+    decoded coordinates; `one_thread`: the reference launch scripts pin OMP_NUM_THREADS=1; `all_cores`: several trajectories in flight,
+    one worker process per group of threads."""
+    import torch as th
+    from oracle import harness
+    host_cores = os.cpu_count() or 1
+    one = 1 if method == "ODE" else 2  # the reference evaluates the network twice per SDE step (drift and score)
+    # trajectory 0 of the GPU run: same seeded weights, the very tensors the HIP path sampled from
+    run = cpu_oracle_runner(args.workload, (init[:1].cpu(), mk["x_cond"][:1].cpu(), mk["x_cond_mask"][:1].cpu(),
+                                            mk["y"][:1].cpu() if "y" in mk else None))
+    best, cal = None, {}
+    for c in [c for c in (8, 16, 32, 64, 128) if c <= host_cores] or [host_cores]:
+        th.set_num_threads(c)
+        if best is None:
+            run(one)  # warm-up (allocator, oneDNN primitives)
+        tc = time.perf_counter()
+        run(one)
+        cal[c] = time.perf_counter() - tc
+        if best is None or cal[c] < cal[best]:
+            best = c
+        if cal[c] > 20.0:
+            break
+    th.set_num_threads(best)
+    full = cal[best] / one * n_evals <= 45.0
+    n_sample = n_evals if full else max(2, min(n_evals, int(round(15.0 * one / cal[best]))))
+    tc = time.perf_counter()
+    cpu_final = run(n_sample)
+    el = time.perf_counter() - tc
+    done = n_sample if method == "ODE" else n_sample - 1
+    per_update = el / done
+    parity = None
+    if kw["in_dim"] == 32 and method == "ODE":  # (SDE runs draw their noise on different generators on the two sides)
+        from lam_slide_amd import Sampler, Stage1Decoder
+        from lam_slide_amd.synthetic import seeded_decoder_state_dict
+        skw_n = dict(skw, num_steps=n_sample + 1)
+        mk1 = {k: v[:1] for k, v in mk.items()}
+        hip_final = Sampler(tr, fused=True, seed=1234).get_sample_fn(method, skw_n)(init[:1], net.forward, **mk1)[-1]
+        dsd = seeded_decoder_state_dict(seed=7)
+        dec = Stage1Decoder(dsd, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+        ent = th.arange(21)[None].expand(T, 21)
+        pos_hip = dec.decode(hip_final[0], ent.to(dev)).cpu()
+        pos_cpu = harness.decode(dsd, harness.DecoderShape(), cpu_final[0], ent)
+        parity = {"latents_rel_l2": harness.rel_l2(hip_final.cpu(), cpu_final), "decoded_coord_rel_l2": harness.rel_l2(pos_hip, pos_cpu),
+                  "state_updates": done, "bar": 1e-3,
+                  "what": f"trajectory 0, {done} of {n_evals} state updates, HIP sampler + HIP decode vs CPU oracle sampler + oracle decode"}
+    cpu = {"value": 1.0 / (per_update * n_evals), "unit": "trajectories/s", "cores": best, "kind": "port", "host_cores": host_cores,
+           "calibration_s_per_update": {str(k): round(v / one, 2) for k, v in cal.items()},
+           "sample": f"oracle restatement (pure PyTorch fp32, reference op structure, {one} network evaluation(s) per update), B=1, "
+                     f"{done} of {n_evals} state updates timed ({el:.1f} s) with {best} threads"
+                     + ("" if full else f", extrapolated linearly to {n_evals}"), "parity": parity}
+    # 1 thread (scripts/md17/second-stage.sh pins OMP_NUM_THREADS=1): one update, extrapolated (per-update cost is constant)
+    th.set_num_threads(1)
+    tc = time.perf_counter()
+    run(one)
+    t1 = (time.perf_counter() - tc) / one
+    cpu["one_thread"] = {"value": 1.0 / (t1 * n_evals), "unit": "trajectories/s", "cores": 1,
+                         "sample": f"1 state update timed ({t1:.1f} s), extrapolated linearly to {n_evals}"}
+    th.set_num_threads(best)
+    # all cores: host_cores // best workers, `best` threads each, one trajectory per worker, all in flight together
+    workers = max(1, host_cores // best)
+    n_w = max(one + 1, min(n_evals, int(round(10.0 / per_update))))
+    env = dict(os.environ, OMP_NUM_THREADS=str(best), MKL_NUM_THREADS=str(best))
+    tc = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--cpu-worker", str(n_w), "--cpu-threads", str(best)],
+                              env=env, stdout=subprocess.PIPE, text=True) for _ in range(workers)]
+    res = []
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        if p.returncode == 0:
+            res.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
+    if res:
+        agg = sum(r["updates"] / r["seconds"] for r in res) / n_evals
+        cpu["all_cores"] = {"value": agg, "unit": "trajectories/s", "cores": workers * best, "workers": len(res), "threads_per_worker": best,
+                            "sample": f"{len(res)} trajectories in flight (one worker process each), {res[0]['updates']} state updates per worker, "
+                                      f"{time.perf_counter() - tc:.1f} s wall incl. start-up, extrapolated linearly to {n_evals}"}
+    return cpu
+
+
+def main():
+    args = parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)  # nothing above this line touches a GPU
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -12,7 +12,8 @@
  *   - All calls are asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*), no
  *     internal synchronisation, no host<->device copies.
  *   - Return value 0 = ok, negative = error; lsl_last_error() returns a thread-local message.
- *     Nothing aborts or throws across this boundary.
+ *     Nothing aborts or throws across this boundary (allocation failures and stray C++ exceptions become error codes).
+ *   - Launches go to the device that owns `stream`, whatever the calling thread's current device is.
  *   - Tensors are row-major contiguous.  State layout [B, T, L, C] fp32 exactly as the reference's
  *     LatentSIV3.forward takes it (latent_si_v31.py:168-170).
  */
@@ -131,6 +132,11 @@ int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspac
 int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps,
                const float *noise, int32_t n_noise, uint64_t seed, uint64_t elem_offset, float *trace,
                void *workspace, size_t workspace_bytes, void *stream);
+
+/* Initial state of a sampling call: x[0..n) ~ N(0,1) from the same counter stream as the per-step noise (reserved step index
+ * 0xFFFFFFFF), element e of the call = global element elem_offset + e.  Stands in for `torch.randn_like(x_cond)`
+ * (models/composites/lightning_base.py:231); shard-invariant by construction. */
+int lsl_randn(float *x, uint64_t n, uint64_t seed, uint64_t elem_offset, void *stream);
 
 /* Test hooks: run a single kernel of the path on caller buffers (parity tests of intermediates). */
 int lsl_debug_block(lsl_model *m, int32_t block_index /* 0..2*depth-1 */, const float *h_in, float *h_out,

@@ -20,7 +20,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 EXPORTED = (
     "lsl_version", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
     "lsl_model_set_chunk", "lsl_pass_size", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_debug_block", "lsl_debug_mods",
-    "lsl_profile_enable", "lsl_profile_read",
+    "lsl_profile_enable", "lsl_profile_read", "lsl_randn",
     "lsl_decoder_create", "lsl_decoder_destroy", "lsl_decode_workspace_bytes", "lsl_decode",
     "lsl_encoder_create", "lsl_encoder_destroy", "lsl_encode_workspace_bytes", "lsl_encode",
 )
@@ -123,6 +123,7 @@ def load() -> C.CDLL:
                                     C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_debug_mods.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]
+    lib.lsl_randn.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
     lib.lsl_profile_enable.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.lsl_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.lsl_decoder_create.argtypes = [C.POINTER(DecoderDesc), C.POINTER(DecoderWeights), C.POINTER(C.c_void_p)]

@@ -13,6 +13,14 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define LDS_PTR(T) __attribute__((address_space(3))) T *
 
+// Timing probes (skip loads / MFMAs / epilogue phases: results WRONG) exist only in -DLSL_EXPERIMENTS builds made by tools/;
+// in the product library the test folds to 0 and no environment variable can reach them.
+#ifdef LSL_EXPERIMENTS
+#define LSL_PROBE(v, bit) ((v) & (bit))
+#else
+#define LSL_PROBE(v, bit) 0
+#endif
+
 // 32x32x16 bf16 MFMA, fp32 accumulate.  Operand maps (lane l: r = l & 31, hf = l >> 5):
 //   A[row r][k = 8 hf + j], B[k = 8 hf + j][col r], j = 0..7
 //   C/D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 hf, reg = 0..15
@@ -80,11 +88,11 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // 1.1 GB per launch for 0.25 GB of operands; with nt stores 0.32 GB).  Inline asm on purpose: when a branch selects between
 // __builtin_nontemporal_store and a plain store of the same value, hipcc merges the two and drops the hint.
 __device__ __forceinline__ void store16(void *p, u32x4 v, bool nt) {
-    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     else *reinterpret_cast<u32x4 *>(p) = v;
 }
 __device__ __forceinline__ void store8(void *p, u32x2 v, bool nt) {
-    if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
     else *reinterpret_cast<u32x2 *>(p) = v;
 }
 

@@ -1,6 +1,6 @@
-// Host side of lsl_decode / lsl_encode: the launch sequences of the frozen stage-1 decode and encode (kernels in k_decode.cuh).
+// Host side of lsl_decode / lsl_encode: the launch sequences of the frozen stage-1 decode and encode (kernels in k_decode.hip.h).
 #pragma once
-#include "k_decode.cuh"
+#include "k_decode.hip.h"
 
 struct lsl_encoder {
     lsl_encoder_desc d;

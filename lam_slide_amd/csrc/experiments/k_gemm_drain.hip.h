@@ -1,8 +1,8 @@
-// "Drain" form of the bf16 MFMA GEMM (same product, operand layouts, k order and epilogue arithmetic as k_gemm.cuh -> identical
+// "Drain" form of the bf16 MFMA GEMM (same product, operand layouts, k order and epilogue arithmetic as k_gemm.hip.h -> identical
 // results): the epilogue of tile i runs INSIDE the main loop of tile i+1, so the two phases that add up in the one-tile-at-a-time
 // kernels (MFMA loop + operand waits 214 ms, epilogue 159 ms per step for linear1) share the same wall time.
 //
-// What the ping-pong experiment (k_gemm_pp.cuh) taught: a role that runs on ONE wave per SIMD is latency- and issue-bound.  Here
+// What the ping-pong experiment (k_gemm_pp.hip.h) taught: a role that runs on ONE wave per SIMD is latency- and issue-bound.  Here
 // every wave does both jobs and the two waves of a SIMD stay symmetric: a 256-feature x 128-token tile, 8 waves of 64 x 64
 // (64 accumulator VGPRs), and a second register set `prev` that holds the finished sums of the previous tile.  Each k-tile
 // interval consists of the MFMA block of the current tile (16 MFMAs per wave at BK = 64) and, in 8 of the intervals, one
@@ -14,7 +14,7 @@
 // Shapes: full tiles only (F % 256 == 0, N % 128 == 0: the epilogue stores are unconditional, which keeps the number of vector
 // memory operations per piece fixed); K % 64 == 0.  Other shapes use the plain kernels.
 #pragma once
-#include "k_gemm.cuh"
+#include "../k_gemm.hip.h"
 
 template <class Epi>
 struct GemmDrainCfg {
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_drain(GemmArgs g, Epi epi) {
         srcX = g.X + (size_t)(n_base + lrow) * g.K + lchunk * 8;
     };
     auto issue = [&](int kt, int slot) {
-        if (g.probe & 1) return;
+        if (LSL_PROBE(g.probe, 1)) return;
         char *dst = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < WP; ++i)
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_drain(GemmArgs g, Epi epi) {
         }
     };
     auto mfma_block = [&](int slot) {
-        if (g.probe & 2) return;
+        if (LSL_PROBE(g.probe, 2)) return;
         const char *sb = smem + slot * STAGE;
         auto rd = [&](int ks, bf16x8(&a)[MI], bf16x8(&b)[NJ]) {
 #pragma unroll
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_drain(GemmArgs g, Epi epi) {
         issue(0, 0);
     }
     for (int s = 0; s <= my_tiles; ++s) {  // step s: MAIN loop of tile s (if any) + epilogue of tile s-1 (if any)
-        const bool main = s < my_tiles, have_prev = s > 0 && !(g.probe & 4);
+        const bool main = s < my_tiles, have_prev = s > 0 && !(LSL_PROBE(g.probe, 4));
         if (main) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)

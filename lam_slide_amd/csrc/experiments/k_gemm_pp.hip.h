@@ -1,4 +1,4 @@
-// Ping-pong form of the bf16 MFMA GEMM of k_gemm.cuh (same product, same operand layouts, same k order, same epilogue
+// Ping-pong form of the bf16 MFMA GEMM of k_gemm.hip.h (same product, same operand layouts, same k order, same epilogue
 // arithmetic -> identical results), built to overlap the three phases that the one-tile-at-a-time kernels run back to back
 // (measured on MI355X, profiles/r01_gemm_variants.txt: MFMA loop 171 ms + epilogue 177 ms + barriers 34 ms = the 385 ms of
 // linear1; the phases do not overlap because all 8 waves of a workgroup are in the same phase at any time).
@@ -21,7 +21,7 @@
 // come BEFORE the first prefetch of the next tile in program order, so at the start of a MAIN phase the queue ends with
 // exactly the NS-1 prefetched k-tiles and the usual counted wait applies.
 #pragma once
-#include "k_gemm.cuh"
+#include "../k_gemm.hip.h"
 
 template <int BK, int NS, class Epi>
 struct GemmPPCfg {
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_pp(GemmArgs g, Epi epi) {
         srcX = g.X + (size_t)(n_base + lrow) * g.K + lchunk * 8;
     };
     auto issue = [&](int kt, int slot) {
-        if (g.probe & 1) return;
+        if (LSL_PROBE(g.probe, 1)) return;
         char *dst = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < WP; ++i)
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_pp(GemmArgs g, Epi epi) {
                 asm volatile("" ::: "memory");
                 if (!active) continue;
                 if (kt + NS - 1 < nk) issue(kt + NS - 1, (base + kt + NS - 1) % NS);
-                if (g.probe & 2) continue;
+                if (LSL_PROBE(g.probe, 2)) continue;
                 const char *sb = smem + ((base + kt) % NS) * STAGE;
                 // fragments of sub-step ks+1 are read before the MFMAs of sub-step ks: a role has ONE wave per SIMD
                 bf16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_pp(GemmArgs g, Epi epi) {
             ne = n_base + w4 * 64;
             if (g.stagger & 1) __builtin_amdgcn_s_setprio(0);
         } else {
-            const bool has_prev = p >= 1 && !(g.probe & 4), has_next = p + 1 < my_tiles;
+            const bool has_prev = p >= 1 && !(LSL_PROBE(g.probe, 4)), has_next = p + 1 < my_tiles;
             if (has_next) set_tile(p + 1);
             const int nbase = (base + nk) % NS;  // ring slot of the next tile's k-tile 0
             int lane_e = lane;                   // opaque copy: keeps the pieces' per-lane address arithmetic inside this branch

@@ -12,7 +12,7 @@
 // so every per-query quantity lives on the query's own lane.  q arrives pre-multiplied by
 // hd^-0.5 * log2(e) (linear1 epilogue), so probabilities are exp2(s - max).
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 struct AttnArgs {
     const u16 *qkv;  // [N][3*HHD] bf16 (q | k | v), head-major inside each third
@@ -22,7 +22,7 @@ struct AttnArgs {
     int n_seq;       // number of sequences
     // token of (seq, pos) = (seq / inner) * outer_stride + (seq % inner) + pos * pos_stride
     int inner, outer_stride, pos_stride;
-    int nt;          // streaming stores for the output (common.cuh: store8)
+    int nt;          // streaming stores for the output (common.hip.h: store8)
 };
 
 template <int HDP>

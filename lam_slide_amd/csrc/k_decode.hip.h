@@ -4,7 +4,7 @@
 // The decode is < 0.1 % of the path's FLOPs (a few hundred MFLOP per frame against 13 TFLOP per trajectory), so these are
 // plain fp32 kernels: no bf16 rounding enters the decoded coordinates, the quantity the parity metric is stated on.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 // LayerNorm over the last dimension, one wave per row (nn.LayerNorm: biased variance, eps inside the sqrt).  w == nullptr: no affine.
 __global__ void __launch_bounds__(256) k_dec_ln(float *out, const float *in, const float *w, const float *b, int rows, int D, float eps) {

@@ -18,14 +18,15 @@
 // load-bound.  The epilogue therefore transposes each wave's sub-tile through wave-private LDS (reusing the
 // operand ring) and writes whole 128/256-byte row segments, 16 B per lane.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 struct GemmArgs {
     const u16 *W;  // [F][K] bf16
     const u16 *X;  // [N][K] bf16
     int F, N, K;
     int stagger;  // persistent grids: initial delay of the second half of the workgroups, in units of 8128 cycles
-    int probe;  // TIMING PROBES ONLY (results wrong): bit0 skip operand loads, bit1 skip LDS reads + MFMAs, bit2 skip epilogue
+    int probe;  // timing probes, honoured only in -DLSL_EXPERIMENTS builds (tools/), where they make results wrong: bit0 skip operand
+                // loads, bit1 skip LDS reads + MFMAs, bit2 skip epilogue.  The product library ignores the field.
 };
 
 template <int N>
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
         srcX = g.X + (size_t)(n_base + lrow) * g.K + lchunk * 8;
     };
     auto issue = [&](int kt, int buf) {
-        if (g.probe & 1) return;
+        if (LSL_PROBE(g.probe, 1)) return;
 #pragma unroll
         for (int i = 0; i < WP; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcW + i * piece_step + kt * BK),
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
                 for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
         };
         constexpr int KS = BK / 16;
-        if (g.probe & 2) continue;
+        if (LSL_PROBE(g.probe, 2)) continue;
         if (BK == 32) {
             bf16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
             load_frags(0, a0, b0);
@@ -209,12 +210,12 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
 
     __syncthreads();  // every wave is done with the operand ring
     const int fw = f_base + wf * WF, nw = n_base + wt * WT;
-    prev_full = f_base + BF <= g.F && n_base + BT <= g.N && !(g.probe & 4);
+    prev_full = f_base + BF <= g.F && n_base + BT <= g.N && !LSL_PROBE(g.probe, 4);
     if (PERSIST && v + (int)gridDim.x < ntiles) {  // stream the next tile's first k-tiles while this tile's epilogue runs
         set_tile(v + gridDim.x);
         prologue();
     }
-    if (!(g.probe & 4)) epi.template run<MI, NJ>(acc, stage, fw, nw, lane, g.F, g.N);
+    if (!LSL_PROBE(g.probe, 4)) epi.template run<MI, NJ>(acc, stage, fw, nw, lane, g.F, g.N);
     }
 }
 
@@ -266,7 +267,7 @@ struct EpiLinear1 {
             const int f = fs + 8 * c;         // this lane's 8 features in phase B
             const bool f_ok = f < F;
             const int sec_out = f / HHD;      // 0 q, 1 k, 2 v, >= 3 mlp
-            const int sec = (probe & 8) ? 2 : sec_out;
+            const int sec = LSL_PROBE(probe, 8) ? 2 : sec_out;
             const int d = f & (HDP - 1);      // channel of the first feature inside its head (sections start on heads)
             float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, s0 = b0, s1 = b0;
             if (f_ok) {
@@ -319,7 +320,7 @@ struct EpiLinear1 {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
                     }
-                    if (f_ok && n < N && !(probe & 16)) {
+                    if (f_ok && n < N && !LSL_PROBE(probe, 16)) {
                         const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
                         u16 *dst = sec_out < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
                         store16(dst, pk, probe & 32);
@@ -328,7 +329,7 @@ struct EpiLinear1 {
             }
         }
     }
-    // ---- the same epilogue as 16 software-pipelined pieces of a 128-feature x 64-token wave tile (k_gemm_pp.cuh), where the
+    // ---- the same epilogue as 16 software-pipelined pieces of a 128-feature x 64-token wave tile (k_gemm_pp.hip.h), where the
     // epilogue runs on ONE wave per SIMD and nothing but the wave's own instruction stream can hide latency.
     // Piece C = rows 16 (C & 1) .. +15 of the 32 x 32 accumulator tile [i = C >> 2][j = (C >> 1) & 1].  The tile is transposed
     // through 4 KiB of wave-private LDS (fp32, layout = swz_bk<64>: 32 token rows x 8 chunks of 4 features); in phase B a lane
@@ -350,7 +351,7 @@ struct EpiLinear1 {
         constexpr int i = C >> 2, j = (C >> 1) & 1, hb = C & 1;
         const int r = lane & 31, hf = lane >> 5, tr = lane >> 2, c = lane & 3;
         const int f = f_wave + i * 32 + 8 * c;
-        const int sec = (probe & 8) ? 2 : (f >= HHD) + (f >= 2 * HHD) + (f >= 3 * HHD);
+        const int sec = LSL_PROBE(probe, 8) ? 2 : (f >= HHD) + (f >= 2 * HHD) + (f >= 3 * HHD);
         const int d = f & (HDP - 1);
         // every load below is unconditional (addresses clamped into the tables, unused values ignored by piece<C>): a load
         // inside a divergent branch gets its s_waitcnt at the end of that branch, i.e. right here instead of one piece later.
@@ -383,7 +384,7 @@ struct EpiLinear1 {
         const int f = f_wave + i * 32 + 8 * c;
         const bool f_ok = f < F;
         const int sec_out = (f >= HHD) + (f >= 2 * HHD) + (f >= 3 * HHD);  // 0 q, 1 k, 2 v, 3 mlp
-        const int sec = (probe & 8) ? 2 : sec_out;
+        const int sec = LSL_PROBE(probe, 8) ? 2 : sec_out;
         const int n = n_wave + j * 32 + 16 * hb + tr;
         const int fc = min(f, F - 8), d = f & (HDP - 1);
         const float4 b0 = *reinterpret_cast<const float4 *>(bias + fc), b1 = *reinterpret_cast<const float4 *>(bias + fc + 4);
@@ -415,7 +416,7 @@ struct EpiLinear1 {
         // the next piece's rows / tables are requested once this piece's arithmetic no longer needs the current ones (no copies
         // of the pipe registers); they have the rest of the interval to arrive
         if (C + 1 < 4 * MI) fetch<(C + 1) % (4 * MI)>(acc, stage, f_wave, n_wave, lane, F, N, k);
-        if (f_ok && n < N && !(probe & 16)) {
+        if (f_ok && n < N && !LSL_PROBE(probe, 16)) {
             const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
             u16 *dst = sec_out < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
             *reinterpret_cast<u32x4 *>(dst) = pk;  // 64 contiguous bytes per token row: half lines, no streaming stores (they need whole lines)
@@ -474,7 +475,7 @@ struct EpiLinear2 {
             }
         }
     }
-    // ---- 16 software-pipelined pieces of a 128-feature x 64-token wave tile (k_gemm_pp.cuh; see EpiLinear1::Pipe): piece C =
+    // ---- 16 software-pipelined pieces of a 128-feature x 64-token wave tile (k_gemm_pp.hip.h; see EpiLinear1::Pipe): piece C =
     // rows 16 (C & 1) .. +15 of the accumulator tile [i = C >> 2][j = (C >> 1) & 1], staged through 4 KiB of LDS; a lane owns 4
     // features of one token, 8 token rows per instruction, two instructions per piece.  The h rows of piece C+1 are requested
     // while piece C computes.
@@ -533,7 +534,7 @@ struct EpiLinear2 {
 };
 
 
-// The piece form of an epilogue (Epi::fetch / Epi::piece, written for k_gemm_pp.cuh) run back to back as the epilogue of the
+// The piece form of an epilogue (Epi::fetch / Epi::piece, written for k_gemm_pp.hip.h) run back to back as the epilogue of the
 // one-tile-at-a-time kernel: 4 KiB of staging per wave instead of 8, which is what lets a PERSISTENT 256 x 256 kernel hold two
 // 64-deep k-tiles (128 KiB) plus the staging of its 8 waves in the 160 KiB of LDS, and the software prefetch of the next
 // piece's LDS rows / tables.  Wave tile must be 128 features x 64 tokens.

@@ -2,7 +2,7 @@
 // embedding, LayerNorm+modulate, output projection fused with the sampler's state update, device noise.
 // These carry < 1 % of the FLOPs and stay in fp32 on purpose ("Accuracy target").
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 // ---------------------------------------------------------------------------------------------------
 // RoPE table: tab[p][j] = (cos, sin)(p * theta^(-2j/hd)), angle in fp64 then rounded (mmdit.py:75-82).
@@ -370,6 +370,15 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
     float sn, cs;
     __sincosf(6.283185307179586f * u2, &sn, &cs);
     return (elem & 1) ? rad * sn : rad * cs;
+}
+
+// Initial state of a sampling call, x_0 ~ N(0, 1) (lightning_base.py:231 torch.randn_like(x_cond)): the same documented stream as the
+// per-step noise, under the reserved step index LSL_INIT_STEP, so that a sharded run (elem_offset = global index of the rank's first
+// element) draws exactly the slice of the unsharded run.
+constexpr unsigned LSL_INIT_STEP = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(256) k_randn(float *x, unsigned long long n, unsigned long long seed, unsigned step, unsigned long long elem_offset) {
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * 256)
+        x[e] = philox_normal(seed, step, elem_offset + e);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -14,10 +14,16 @@
 #include <cstring>
 #include <vector>
 
-#include "k_attn.cuh"
-#include "k_gemm_pp.cuh"
-#include "k_gemm_drain.cuh"
-#include "k_small.cuh"
+#include <atomic>
+#include <new>
+
+#include "k_attn.hip.h"
+#include "k_gemm.hip.h"
+#include "k_small.hip.h"
+#ifdef LSL_EXPERIMENTS  // measured-and-rejected GEMM structures, built only by tools/build_experiments.sh (never in the product library)
+#include "experiments/k_gemm_pp.hip.h"
+#include "experiments/k_gemm_drain.hip.h"
+#endif
 
 namespace {
 
@@ -78,6 +84,8 @@ struct lsl_model {
     };
     std::vector<GraphEntry> graphs;
     std::vector<std::vector<unsigned char>> seen;  // argument sets that ran eagerly once (capture happens on their second appearance)
+    std::vector<std::vector<unsigned char>> uncapturable;  // argument sets whose capture failed: never tried again
+    bool graph_stream_failed = false;                      // the internal capture stream could not be created: no further attempts
     unsigned long long graph_clock = 0;
     hipStream_t graph_stream = nullptr;  // capture happens on this internal stream (the caller's may be the legacy default stream, which
                                          // cannot be captured); the instantiated graph is launched on the caller's stream
@@ -121,6 +129,7 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
 }
 
 int env_int(const char *name, int dflt);
+int tune_int(const char *name, int dflt);
 int n_lanes() {
     static const int l = env_int("LSL_LANES", 1);
     return l >= 2 ? 2 : 1;
@@ -146,6 +155,38 @@ template <typename K>
 void allow_lds(K kernel, size_t bytes) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+// The dynamic-LDS attribute is a property of (kernel, device): one flag per device ordinal and per call site.
+struct DevOnce {
+    std::atomic<unsigned long long> bits{0};
+    bool first() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (bits.load(std::memory_order_relaxed) & bit) return false;
+        bits.fetch_or(bit, std::memory_order_relaxed);
+        return true;
+    }
+};
+#define LSL_ALLOW_LDS(kern, bytes)                  \
+    do {                                            \
+        static DevOnce once_;                       \
+        if (once_.first()) allow_lds(kern, bytes);  \
+    } while (0)
+
+// Calls may arrive with a current device other than the stream's (a model used on a second GPU of the process): launches,
+// attributes and the CU count must follow the STREAM's device.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(hipStream_t st) {
+        int cur = 0, want = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return;
+        if (hipStreamGetDevice(st, &want) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (want != cur && hipSetDevice(want) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 
 // ---- launch helpers -------------------------------------------------------------------------------
 
@@ -155,10 +196,10 @@ int env_int(const char *name, int dflt);
 template <int NE, int VEC>
 void launch_ln_mod_t(u16 *a, const float *h, const float *shift, const float *scale, int stride, int n, int tpt, hipStream_t st) {
     if constexpr (NE % 4 == 0) {
-        static const int persist = env_int("LSL_LN_PERSIST", 16);  // workgroups per CU of the persistent form; 0 = one wave per token
+        static const int persist = tune_int("LSL_LN_PERSIST", 16);  // workgroups per CU of the persistent form; 0 = one wave per token
         if (persist > 0) {
             const int grid = std::min((n + 3) / 4, device_cus() * persist);
-            static const int nt = (env_int("LSL_NT", 3) >> 3) & 1;
+            static const int nt = (tune_int("LSL_NT", 3) >> 3) & 1;
             hipLaunchKernelGGL((k_ln_modulate_v4<NE>), dim3(grid), dim3(256), 0, st, a, h, shift, scale, stride, n, tpt, nt);
             return;
         }
@@ -176,22 +217,22 @@ template <int NE, int VEC>
 void launch_head_t(float *x, float *out, const float *h, const float *shift, const float *scale, int stride, const float *Wo,
                    const float *bo, int n, int C, int tpt, int do_step, float ax, float am, float aw, const float *noise,
                    unsigned long long seed, unsigned step, unsigned long long eo, float *trace, hipStream_t st) {
-    static const int mfma = env_int("LSL_HEAD_MFMA", 1);  // 0: the scalar-FMA kernel (A/B measurements)
-    if (mfma) {
-        auto kern = k_head_step_mfma<NE, VEC>;
-        constexpr size_t lds = head_mfma_lds_bytes<NE>();
-        static bool once = (allow_lds(kern, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, device_cus())), dim3(256), lds, st, x, out, h, shift, scale, stride,
-                           Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
+#ifdef LSL_EXPERIMENTS
+    static const int mfma = tune_int("LSL_HEAD_MFMA", 1);  // 0: the scalar-FMA kernel (A/B measurements)
+    if (!mfma) {
+        auto kern = k_head_step<NE, VEC>;
+        constexpr size_t lds = head_lds_bytes<NE>();
+        LSL_ALLOW_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, 256)), dim3(256), lds, st, x, out, h, shift, scale, stride, Wo, bo, n,
+                           C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
         return;
     }
-    auto kern = k_head_step<NE, VEC>;
-    constexpr size_t lds = head_lds_bytes<NE>();
-    static bool once = (allow_lds(kern, lds), true);
-    (void)once;
-    hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, 256)), dim3(256), lds, st, x, out, h, shift, scale, stride, Wo, bo, n,
-                       C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
+#endif
+    auto kern = k_head_step_mfma<NE, VEC>;
+    constexpr size_t lds = head_mfma_lds_bytes<NE>();
+    LSL_ALLOW_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, device_cus())), dim3(256), lds, st, x, out, h, shift, scale, stride,
+                       Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
 }
 
 #define DISPATCH_D(D, FN, ...)                          \
@@ -223,14 +264,27 @@ int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+// Kernel-selection / timing knobs (LSL_GEMM*, LSL_NT, LSL_STAGGER, LSL_PROBE, ...): read from the environment only in
+// -DLSL_EXPERIMENTS builds; the product library always runs its measured defaults.
+int tune_int(const char *name, int dflt) {
+#ifdef LSL_EXPERIMENTS
+    return env_int(name, dflt);
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
-int device_cus() {
-    static const int n = [] {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
-        return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    }();
+int device_cus() {  // of the current device (entry points switch to the stream's device first)
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int n = cache[dev & 63].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n <= 0) n = 256;
+    cache[dev & 63].store(n, std::memory_order_relaxed);
     return n;
 }
 
@@ -238,8 +292,7 @@ template <int BF, int BT, int NWF, int NWT, int BK, int NS, bool PERSIST, class 
 void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     auto kern = k_gemm_glds<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>;
     constexpr size_t lds = GemmCfg<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>::lds_bytes;
-    static bool once = (allow_lds(kern, lds), true);
-    (void)once;
+    LSL_ALLOW_LDS(kern, lds);
     const int tiles = ((g.N + BT - 1) / BT) * ((g.F + BF - 1) / BF);
     int grid = tiles;
     if (PERSIST) {  // as many workgroups as fit at once (LDS-limited), a multiple of 8 so the XCD mapping stays regular
@@ -251,12 +304,12 @@ void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWF * NWT * 64), lds, st, g, epi);
 }
 
+#ifdef LSL_EXPERIMENTS
 template <int BK, int NS, int NB, class Epi>
 void launch_gemm_pp_t(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     auto kern = k_gemm_pp<BK, NS, NB, Epi>;
     constexpr size_t lds = GemmPPCfg<BK, NS, Epi>::lds_bytes;
-    static bool once = (allow_lds(kern, lds), true);
-    (void)once;
+    LSL_ALLOW_LDS(kern, lds);
     const int tiles = ((g.N + 255) / 256) * ((g.F + 127) / 128);
     int grid = device_cus();
     grid -= grid % 8;
@@ -264,14 +317,13 @@ void launch_gemm_pp_t(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g, epi);
 }
 
-// epilogue of tile i inside the main loop of tile i+1 (k_gemm_drain.cuh); false when the shape is outside what it covers
+// epilogue of tile i inside the main loop of tile i+1 (k_gemm_drain.hip.h); false when the shape is outside what it covers
 template <class Epi>
 bool launch_gemm_drain(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     if (g.F % 256 != 0 || g.N % 128 != 0 || g.K % 64 != 0 || g.K / 64 < 2) return false;
     auto kern = k_gemm_drain<Epi>;
     constexpr size_t lds = GemmDrainCfg<Epi>::lds_bytes;
-    static bool once = (allow_lds(kern, lds), true);
-    (void)once;
+    LSL_ALLOW_LDS(kern, lds);
     const int tiles = (g.N / 128) * (g.F / 256);
     int grid = device_cus();
     grid -= grid % 8;
@@ -280,7 +332,7 @@ bool launch_gemm_drain(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     return true;
 }
 
-// ping-pong halves (k_gemm_pp.cuh); false when the shape is outside what the schedule covers
+// ping-pong halves (k_gemm_pp.hip.h); false when the shape is outside what the schedule covers
 template <int BK, int NS, class Epi>
 bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     if (g.K % BK != 0 || g.F % 32 != 0) return false;
@@ -291,6 +343,8 @@ bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     else launch_gemm_pp_t<BK, NS, 4>(g, epi, st);
     return true;
 }
+
+#endif  // LSL_EXPERIMENTS
 
 // GEMM tiling (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
 //   (features x tokens, waves, BK x ring stages):
@@ -304,30 +358,32 @@ bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 //   13 256x128  4 waves 32x2, persistent, two workgroups per CU
 //   15 256x256 16 waves 64x2 (64x64 per wave, 4 waves/SIMD: the light linear2 epilogue fits the 128-VGPR budget and the
 //      extra occupancy hides load / store latency)
-// 20-22: ping-pong halves (k_gemm_pp.cuh).  Default (-1): 12 for linear1 (5 when K < 512 or not a multiple of 128, 6 when not a multiple of 64), 7 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
+// 20-22: ping-pong halves (k_gemm_pp.hip.h).  Default (-1): 12 for linear1 (5 when K < 512 or not a multiple of 128, 6 when not a multiple of 64), 7 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
 // every variant that was tried, including the ones no longer compiled in).
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi_in, hipStream_t st, int hhd = 32) {
-    static const int forced_all = env_int("LSL_GEMM", -1);
-    static const int forced_1 = env_int("LSL_GEMM1", -1), forced_2 = env_int("LSL_GEMM2", -1);  // per GEMM: linear1 / linear2
+    static const int forced_all = tune_int("LSL_GEMM", -1);
+    static const int forced_1 = tune_int("LSL_GEMM1", -1), forced_2 = tune_int("LSL_GEMM2", -1);  // per GEMM: linear1 / linear2
     const int forced_one = std::is_same<Epi, EpiLinear2>::value ? forced_2 : forced_1;
     const int forced = forced_one >= 0 ? forced_one : forced_all;
     // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
     const int ragged_variant = std::is_same<Epi, EpiLinear2>::value && K % 64 == 0 ? 11 : 10;  // measured on the D = 384 / 128 models
     const int variant = forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 && K >= 512 ? 12 : K % 64 == 0 ? 5 : 6));
-    static const int probe = env_int("LSL_PROBE", 0);
-    static const int stagger = env_int("LSL_STAGGER", 0);
+    static const int probe = tune_int("LSL_PROBE", 0);
+    static const int stagger = tune_int("LSL_STAGGER", 0);
     GemmArgs g{W, X, F, N, K, stagger, probe};
     // LSL_NT bit 0: linear1 output, bit 1: linear2 residual update, bit 2: attention output, bit 3: LayerNorm+modulate output
-    static const int nt = env_int("LSL_NT", 3);
+    static const int nt = tune_int("LSL_NT", 3);
     Epi epi = epi_in;
     epi.probe = probe | ((nt >> (std::is_same<Epi, EpiLinear2>::value ? 1 : 0)) & 1 ? 32 : 0);
     const bool pp_ok = !std::is_same<Epi, EpiLinear2>::value ? hhd % 32 == 0 : true;  // linear1 sections start on 32-feature tiles
+#ifdef LSL_EXPERIMENTS
     if (variant == 30 && launch_gemm_drain(g, epi, st)) return;
     if (variant == 20 && pp_ok && launch_gemm_pp<32, 4>(g, epi, st)) return;
     if (variant == 21 && pp_ok && launch_gemm_pp<64, 2>(g, epi, st)) return;
     if (variant == 22 && pp_ok && launch_gemm_pp<64, 3>(g, epi, st)) return;
+#endif
     if (variant == 12 && K % 128 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, epi, st);  // 5 made persistent (staging in ring slot 1)
     if (variant == 7 && F % 32 == 0 && pp_ok && K % 128 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, EpiPieces<Epi>(epi), st);  // persistent, 64-deep k-tiles, piece epilogue
     if (variant == 8 && F % 32 == 0 && pp_ok) return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, EpiPieces<Epi>(epi), st);  // variant 6 with the piece epilogue
@@ -335,7 +391,9 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
         case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
         case 11: return launch_gemm_glds<128, 128, 2, 2, 64, 2, false>(g, epi, st);
+#ifdef LSL_EXPERIMENTS
         case 13: return launch_gemm_glds<256, 128, 2, 2, 32, 2, true>(g, epi, st);
+#endif
         case 15: return launch_gemm_glds<256, 256, 4, 4, 64, 2, false>(g, epi, st);
         default: return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, epi, st);
     }
@@ -345,8 +403,7 @@ template <int HDP, int NW, int ITEMS, int NKT>
 void launch_attention_rows(const AttnArgs &a, hipStream_t st) {
     auto kern = k_attention_rows<HDP, NW, ITEMS, NKT>;
     const size_t lds = (size_t)ITEMS * 2 * (NKT > 0 ? NKT * 32 : (a.S + 31) & ~31) * HDP * 2;
-    static bool once = (allow_lds(kern, NKT > 0 ? lds : (size_t)160 * 1024), true);
-    (void)once;
+    LSL_ALLOW_LDS(kern, NKT > 0 ? lds : (size_t)160 * 1024);
     const long items = (long)a.n_seq * a.H;
     hipLaunchKernelGGL(kern, dim3((unsigned)((items + ITEMS - 1) / ITEMS)), dim3(NW * 64), lds, st, a);
 }
@@ -354,7 +411,7 @@ void launch_attention_rows(const AttnArgs &a, hipStream_t st) {
 template <int HDP>
 void launch_attention_t(const AttnArgs &a, hipStream_t st) {
     const int Sp = (a.S + 31) & ~31;
-    static const int online = env_int("LSL_ATTN_ONLINE", 0);  // 1: force the online-softmax kernel (A/B measurements)
+    static const int online = tune_int("LSL_ATTN_ONLINE", 0);  // 1: force the online-softmax kernel (A/B measurements)
     if (!online && a.S <= 8) {  // one lane per (query, head), no MFMA padding
         const long lanes = (long)a.n_seq * a.S * a.H;
         hipLaunchKernelGGL((k_attention_tiny<HDP>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, a);
@@ -378,13 +435,11 @@ void launch_attention_t(const AttnArgs &a, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3((unsigned)((items + 1) / 2)), dim3(256), 2 * per_item, st, a);
     } else if (Sp <= 512) {
         auto kern = k_attention<HDP, 4, 1>;
-        static bool once = (allow_lds(kern, 65536), true);
-        (void)once;
+        LSL_ALLOW_LDS(kern, 65536);
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(256), per_item, st, a);
     } else {
         auto kern = k_attention<HDP, 8, 1>;
-        static bool once = (allow_lds(kern, 160 * 1024), true);
-        (void)once;
+        LSL_ALLOW_LDS(kern, 160 * 1024);
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), per_item, st, a);
     }
 }
@@ -468,7 +523,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
         launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st, m->HHD);
     }
     m->prof.end(0, st);
-    static const int nt_mask = env_int("LSL_NT", 3);
+    static const int nt_mask = tune_int("LSL_NT", 3);
     AttnArgs aa;
     aa.nt = (nt_mask >> 2) & 1;
     aa.qkv = ws.qkv;
@@ -552,14 +607,14 @@ int check_call(const lsl_model *m, const lsl_io *io, size_t ws_bytes, void *ws, 
 
 }  // namespace
 
-#include "decode_host.cuh"
+#include "decode_host.hip.h"
 
 extern "C" {
 
 int lsl_version(void) { return LSL_VERSION; }
 const char *lsl_last_error(void) { return g_err; }
 
-int lsl_model_create(const lsl_model_desc *desc, lsl_model **out) {
+int lsl_model_create(const lsl_model_desc *desc, lsl_model **out) try {
     if (!desc || !out) return fail(-1, "null argument");
     const lsl_model_desc &d = *desc;
     if (d.heads <= 0 || d.hidden % d.heads != 0)
@@ -583,9 +638,13 @@ int lsl_model_create(const lsl_model_desc *desc, lsl_model **out) {
     m->MODW = (6 * d.depth + 2) * d.hidden;
     *out = m;
     return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
-int lsl_model_set_weights(lsl_model *m, const lsl_weights *w) {
+int lsl_model_set_weights(lsl_model *m, const lsl_weights *w) try {
     if (!m || !w || !w->blocks) return fail(-1, "null argument");
     const void *req[] = {w->x_in_w, w->x_in_b, w->cond_w, w->cond_b, w->mask_emb, w->time_freqs, w->time_w1, w->time_b1,
                          w->time_w2, w->time_b2, w->mod_w, w->mod_b, w->out_w, w->out_b};
@@ -602,7 +661,12 @@ int lsl_model_set_weights(lsl_model *m, const lsl_weights *w) {
         if (g.exec) hipGraphExecDestroy(g.exec);
     m->graphs.clear();
     m->seen.clear();
+    m->uncapturable.clear();
     return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
 void lsl_model_destroy(lsl_model *m) {
@@ -618,7 +682,7 @@ void lsl_model_destroy(lsl_model *m) {
     delete m;
 }
 
-int lsl_profile_enable(lsl_model *m, int32_t kernel, int32_t max_launches) {
+int lsl_profile_enable(lsl_model *m, int32_t kernel, int32_t max_launches) try {
     if (!m) return fail(-1, "null model");
     m->prof.clear();
     if (kernel < 0 || max_launches <= 0) return 0;
@@ -628,6 +692,10 @@ int lsl_profile_enable(lsl_model *m, int32_t kernel, int32_t max_launches) {
     m->prof.kernel = kernel;
     m->prof.cap = max_launches;
     return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
 int lsl_profile_read(lsl_model *m, double *total_ms, int32_t *launches) {
@@ -650,13 +718,18 @@ static void drop_graphs(lsl_model *m) {
         if (g.exec) hipGraphExecDestroy(g.exec);
     m->graphs.clear();
     m->seen.clear();
+    m->uncapturable.clear();
 }
 
-int lsl_model_set_chunk(lsl_model *m, int32_t c) {
+int lsl_model_set_chunk(lsl_model *m, int32_t c) try {
     if (!m || c < 0) return fail(-1, "bad argument");
     m->chunk = c;
     drop_graphs(m);
     return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
 int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
@@ -669,7 +742,8 @@ size_t lsl_workspace_bytes(const lsl_model *m, int32_t B, int32_t T, int32_t L) 
     return carve(m, nullptr, default_chunk(m, B, T, L), T, L).bytes * n_lanes();
 }
 
-int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspace_bytes, void *stream) {
+int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspace_bytes, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
     int chunk = 0;
     if (int rc = check_call(m, io, workspace_bytes, workspace, &chunk)) return rc;
     if (!io->t || !io->out) return fail(-3, "t and out are required");
@@ -686,13 +760,18 @@ int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspac
             return rc;
     }
     return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
 static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, uint64_t seed,
                           uint64_t elem_offset, float *trace, void *workspace, int chunk, hipStream_t st);
 
 int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, int32_t n_noise, uint64_t seed,
-               uint64_t elem_offset, float *trace, void *workspace, size_t workspace_bytes, void *stream) {
+               uint64_t elem_offset, float *trace, void *workspace, size_t workspace_bytes, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
     int chunk = 0;
     if (int rc = check_call(m, io, workspace_bytes, workspace, &chunk)) return rc;
     if (!steps || n_steps <= 0) return fail(-3, "steps required");
@@ -727,11 +806,17 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
                 if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail(-10, "hipGraphLaunch failed");
                 return 0;
             }
-        bool second = false;
+        bool second = false, bad = m->graph_stream_failed;
+        for (auto &k : m->uncapturable) bad |= (k == key);
         for (auto &k : m->seen) second |= (k == key);
-        if (second) {
+        if (bad) {
+            // capture failed before for this argument set (or no capture stream): eager from now on
+        } else if (second) {
             hipGraph_t graph = nullptr;
-            if (!m->graph_stream && hipStreamCreateWithFlags(&m->graph_stream, hipStreamNonBlocking) != hipSuccess) m->graph_stream = nullptr;
+            if (!m->graph_stream && hipStreamCreateWithFlags(&m->graph_stream, hipStreamNonBlocking) != hipSuccess) {
+                m->graph_stream = nullptr;
+                m->graph_stream_failed = true;
+            }
             hipStream_t cs = m->graph_stream;
             if (cs && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 const int rc = sample_enqueue(m, io, steps, n_steps, noise, seed, elem_offset, trace, workspace, chunk, cs);
@@ -756,15 +841,24 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
                 }
                 if (graph) hipGraphDestroy(graph);
             }
-            (void)hipGetLastError();  // capture not possible: forget the error and run eagerly (this argument set is not tried again)
-            for (auto &k : m->seen)
-                if (k == key) k.clear();
+            (void)hipGetLastError();  // capture not possible: forget the error, run eagerly, and never try this argument set again
+            for (size_t i = 0; i < m->seen.size(); ++i)
+                if (m->seen[i] == key) {
+                    m->seen.erase(m->seen.begin() + i);
+                    break;
+                }
+            if (m->uncapturable.size() >= 16) m->uncapturable.erase(m->uncapturable.begin());
+            m->uncapturable.push_back(key);
         } else {
             if (m->seen.size() >= 16) m->seen.erase(m->seen.begin());
             m->seen.push_back(key);
         }
     }
     return sample_enqueue(m, io, steps, n_steps, noise, seed, elem_offset, trace, workspace, chunk, st);
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
 static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, uint64_t seed,
@@ -825,8 +919,25 @@ static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step *steps,
     return 0;
 }
 
+// x_0 ~ N(0, 1) from the documented counter stream (k_small.hip.h: k_randn); the reference draws torch.randn_like(x_cond)
+// (lightning_base.py:231), whose generator stream cannot be reproduced off an NVIDIA/torch build anyway.
+int lsl_randn(float *x, uint64_t n, uint64_t seed, uint64_t elem_offset, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
+    if (!x && n) return fail(-1, "null argument");
+    if (!n) return 0;
+    const unsigned long long blocks = (n + 255) / 256;
+    const unsigned grid = (unsigned)std::min<unsigned long long>(blocks, (unsigned long long)device_cus() * 16);
+    hipLaunchKernelGGL(k_randn, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned long long)n, (unsigned long long)seed, LSL_INIT_STEP,
+                       (unsigned long long)elem_offset);
+    LSL_CHECK_LAUNCH("lsl_randn");
+    return 0;
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
+}
+
 int lsl_debug_block(lsl_model *m, int32_t bi, const float *h_in, float *h_out, const float *mods, int32_t B, int32_t T, int32_t L,
-                    void *workspace, size_t workspace_bytes, void *stream) {
+                    void *workspace, size_t workspace_bytes, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
     if (!m || !m->has_weights) return fail(-2, "weights not set");
     if (bi < 0 || bi >= 2 * m->d.depth) return fail(-3, "block index out of range");
     const size_t need = carve(m, nullptr, B, T, L).bytes;
@@ -837,10 +948,15 @@ int lsl_debug_block(lsl_model *m, int32_t bi, const float *h_in, float *h_out, c
     const size_t bytes = (size_t)B * T * L * m->d.hidden * 4;
     if (h_in != h_out) hipMemcpyAsync(h_out, h_in, bytes, hipMemcpyDeviceToDevice, st);
     return run_block(m, ws, bi, h_out, mods, m->MODW, B, T, L, st);
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
 int lsl_debug_mods(lsl_model *m, const float *t, const float *y, int32_t B, float *vec_out, float *mods_out, void *workspace,
-                   size_t workspace_bytes, void *stream) {
+                   size_t workspace_bytes, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
     if (!m || !m->has_weights) return fail(-2, "weights not set");
     const size_t need = carve(m, nullptr, B, 1, 1).bytes;
     if (!workspace || workspace_bytes < need) return fail(-4, "workspace too small: need %zu bytes", need);
@@ -850,9 +966,13 @@ int lsl_debug_mods(lsl_model *m, const float *t, const float *y, int32_t B, floa
         if (int rc = run_yemb(m, ws, y, B, st)) return rc;
     }
     return run_mods(m, ws, t, 0.0f, y ? ws.yemb : nullptr, B, vec_out, mods_out, st);
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
-int lsl_decoder_create(const lsl_decoder_desc *desc, const lsl_decoder_weights *w, lsl_decoder **out) {
+int lsl_decoder_create(const lsl_decoder_desc *desc, const lsl_decoder_weights *w, lsl_decoder **out) try {
     if (!desc || !w || !out) return fail(-1, "null decoder argument");
     const lsl_decoder_desc &d = *desc;
     if (d.in_dim % 4 || d.dim_latent % 4 || d.dim_query % 4 || d.dim_emb % 4 || (d.heads_latent * d.dim_head_latent) % 4 ||
@@ -862,7 +982,8 @@ int lsl_decoder_create(const lsl_decoder_desc *desc, const lsl_decoder_weights *
     if (d.act != 1 && d.act != 2) return fail(-3, "decoder activation must be 1 (erf GELU) or 2 (tanh GELU)");
     if (d.num_block_attn < 0 || d.num_block_cross < 0 || d.out_dim < 1 || d.n_entities < 1 || d.num_split < 0) return fail(-3, "bad decoder description");
     if (d.num_split > 1 && (!w->ext_w || !w->ext_b)) return fail(-2, "decoder with num_split > 1 needs the extender weights");
-    lsl_decoder *dec = new lsl_decoder();
+    lsl_decoder *dec = new (std::nothrow) lsl_decoder();
+    if (!dec) return fail(-5, "out of host memory");
     dec->d = d;
     dec->w = *w;
     if (d.num_block_attn) dec->self_blocks.assign(w->self_blocks, w->self_blocks + d.num_block_attn);
@@ -871,6 +992,10 @@ int lsl_decoder_create(const lsl_decoder_desc *desc, const lsl_decoder_weights *
     dec->w.cross_blocks = dec->cross_blocks.data();
     *out = dec;
     return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
 void lsl_decoder_destroy(lsl_decoder *d) { delete d; }
@@ -882,7 +1007,8 @@ size_t lsl_decode_workspace_bytes(const lsl_decoder *d, int32_t frames, int32_t 
 
 // Decoder.forward (decoder.py:88-102) after post_quant (lightning_base.py:28-31,42-44)
 int lsl_decode(lsl_decoder *dec, const float *z, const int64_t *entities, int32_t frames, int32_t L, int32_t A, float *out, void *workspace,
-               size_t workspace_bytes, void *stream) {
+               size_t workspace_bytes, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
     if (!dec || !z || !entities || !out) return fail(-1, "null decode argument");
     if (frames <= 0 || L <= 0 || A <= 0) return fail(-3, "decode: empty input");
     const lsl_decoder_desc &d = dec->d;
@@ -914,9 +1040,13 @@ int lsl_decode(lsl_decoder *dec, const float *z, const int64_t *entities, int32_
     dec_dense(0, out, ws.hid, w.head_w2, w.head_b2, nullptr, na, d.dim_query, d.out_dim, st);
     LSL_CHECK_LAUNCH("lsl_decode");
     return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
-int lsl_encoder_create(const lsl_encoder_desc *desc, const lsl_encoder_weights *w, lsl_encoder **out) {
+int lsl_encoder_create(const lsl_encoder_desc *desc, const lsl_encoder_weights *w, lsl_encoder **out) try {
     if (!desc || !w || !out) return fail(-1, "null encoder argument");
     const lsl_encoder_desc &d = *desc;
     if (d.dim_input % 4 || d.dim_emb % 4 || d.dim_latent % 4 || (d.heads_latent * d.dim_head_latent) % 4 || (d.heads_cross * d.dim_head_cross) % 4)
@@ -924,7 +1054,8 @@ int lsl_encoder_create(const lsl_encoder_desc *desc, const lsl_encoder_weights *
     if (d.dim_head_latent > 64 || d.dim_head_cross > 64 || d.dim_head_latent < 1 || d.dim_head_cross < 1) return fail(-3, "encoder dim_head must be 1..64");
     if (d.act != 1 && d.act != 2) return fail(-3, "encoder activation must be 1 (erf GELU) or 2 (tanh GELU)");
     if (d.num_block_attn < 0 || d.num_block_cross < 0 || d.num_latents < 1 || d.n_entities < 1) return fail(-3, "bad encoder description");
-    lsl_encoder *enc = new lsl_encoder();
+    lsl_encoder *enc = new (std::nothrow) lsl_encoder();
+    if (!enc) return fail(-5, "out of host memory");
     enc->d = d;
     enc->w = *w;
     if (d.num_block_cross) enc->cross_blocks.assign(w->cross_blocks, w->cross_blocks + d.num_block_cross);
@@ -933,6 +1064,10 @@ int lsl_encoder_create(const lsl_encoder_desc *desc, const lsl_encoder_weights *
     enc->w.self_blocks = enc->self_blocks.data();
     *out = enc;
     return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
 void lsl_encoder_destroy(lsl_encoder *e) { delete e; }
@@ -944,7 +1079,8 @@ size_t lsl_encode_workspace_bytes(const lsl_encoder *e, int32_t frames, int32_t 
 
 // quant(Encoder.forward(x, entities, mask))   (encoder.py:96-103, lightning_base.py:37-40)
 int lsl_encode(lsl_encoder *enc, const float *x, const int64_t *entities, const unsigned char *mask, int32_t frames, int32_t A, float *out,
-               void *workspace, size_t workspace_bytes, void *stream) {
+               void *workspace, size_t workspace_bytes, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
     if (!enc || !x || !entities || !out) return fail(-1, "null encode argument");
     if (frames <= 0 || A <= 0) return fail(-3, "encode: empty input");
     const lsl_encoder_desc &d = enc->d;
@@ -970,6 +1106,10 @@ int lsl_encode(lsl_encoder *enc, const float *x, const int64_t *entities, const 
     dec_ln(out, ws.hid, nullptr, nullptr, nl, d.dim_latent, st);
     LSL_CHECK_LAUNCH("lsl_encode");
     return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
 }
 
 }  // extern "C"

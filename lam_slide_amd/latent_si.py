@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
+from collections import OrderedDict
 from typing import Optional
 
 import torch
@@ -85,6 +87,8 @@ class LatentSIV3(nn.Module):
         reset_parameters: bool = True,
     ):
         super().__init__()
+        from . import dropin
+        dropin.install()  # no-op unless a reference checkout's sampler modules are already imported (dropin.py)
         self.in_dim = in_dim
         self.out_dim = in_dim
         self.n_timesteps = n_timesteps      # accepted and ignored, as in the reference
@@ -121,7 +125,8 @@ class LatentSIV3(nn.Module):
         self._packed: Optional[PackedWeights] = None
         self._packed_key = None
         self._handle = C.c_void_p()
-        self._workspace: Optional[Tensor] = None
+        self._workspaces: "OrderedDict[tuple, Tensor]" = OrderedDict()
+        self._pinned: "OrderedDict[tuple, Tensor]" = OrderedDict()
         self._chunk = 0
         self.last_path = None  # "hip" after a forward, for tests that must prove the native path ran
 
@@ -148,6 +153,12 @@ class LatentSIV3(nn.Module):
             nn.init.constant_(blk.modulation.lin.bias, 0.0)
         nn.init.constant_(self.linear.weight, 0.0)
         nn.init.constant_(self.linear.bias, 0.0)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Also accepts the keys of a backbone that was saved while wrapped by ``torch.compile`` (``_orig_mod.`` prefix; the
+        reference compiles its backbone when ``compile: True``, second_stage/md17.py:53-55)."""
+        from .packing import strip_prefixes
+        return super().load_state_dict(strip_prefixes(state_dict), strict=strict, assign=assign)
 
     # ---- native handle ---------------------------------------------------------------------------------
     def _weights_key(self, device):
@@ -176,22 +187,44 @@ class LatentSIV3(nn.Module):
             _lib.load().lsl_model_set_chunk(self._handle, self._chunk)
 
     def workspace(self, B: int, T: int, L: int, device) -> Tensor:
+        """Scratch of one call.  One buffer per (device, stream): two sampling calls of one model in flight on different streams
+        never share scratch (calls on ONE stream are ordered by the stream).  At most 4 buffers are kept."""
+        device = torch.device(device)
         need = _lib.load().lsl_workspace_bytes(self._handle, B, T, L)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != torch.device(device):
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
-        return self._workspace
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._workspaces[key] = ws
+        self._workspaces.move_to_end(key)
+        while len(self._workspaces) > 4:
+            self._workspaces.popitem(last=False)
+        return ws
 
-    def pinned(self, tag: str, src: Tensor, dtype: torch.dtype) -> Tensor:
-        """A persistent device buffer per (tag, shape) holding a copy of ``src``: the fused sampler hands the library the SAME pointers on
-        every call of a given shape, which is what lets ``lsl_sample`` replay a captured hipGraph instead of re-launching ~40 kernels
-        per state update (the small-batch configs are launch-bound).  One sampling call at a time per model object."""
-        if not hasattr(self, "_pinned"):
-            self._pinned = {}
-        key = (tag, tuple(src.shape), src.device)
+    @staticmethod
+    def graph_replay_enabled() -> bool:
+        return os.environ.get("LSL_GRAPH", "0") not in ("", "0")
+
+    def staged(self, tag: str, src: Tensor, dtype: torch.dtype, device, fresh: bool = False) -> Tensor:
+        """``src`` as a contiguous ``dtype`` tensor on ``device`` for the library.  By default nothing persists: ``fresh`` (the state,
+        which the sampler updates in place) gets a private copy, everything else is passed through when it already has the right layout.
+        Only with hipGraph replay switched on (LSL_GRAPH != 0) the copy goes into a persistent buffer per (tag, shape, device), so that
+        repeated calls hand the library the SAME pointers and ``lsl_sample`` can replay its captured graph; that cache is LRU-bounded
+        (8 buffers) and its users must run one sampling call at a time per model object."""
+        device = torch.device(device)
+        if not self.graph_replay_enabled():
+            out = src.detach().to(device=device, dtype=dtype).contiguous()
+            if fresh and out.data_ptr() == src.data_ptr():
+                out = out.clone()
+            return out
+        key = (tag, tuple(src.shape), device)
         buf = self._pinned.get(key)
         if buf is None:
-            buf = torch.empty(src.shape, dtype=dtype, device=src.device)
+            buf = torch.empty(src.shape, dtype=dtype, device=device)
             self._pinned[key] = buf
+        self._pinned.move_to_end(key)
+        while len(self._pinned) > 8:
+            self._pinned.popitem(last=False)
         buf.copy_(src)
         return buf
 
@@ -210,11 +243,25 @@ class LatentSIV3(nn.Module):
 
     def make_io(self, x: Tensor, x_cond: Tensor, x_cond_mask: Tensor, y: Optional[Tensor], t: Optional[Tensor] = None,
                 out: Optional[Tensor] = None):
+        """Argument block of one library call.  Everything handed over as a pointer is checked here: a tensor on another device (or
+        on the host) would otherwise reach the kernels as a foreign address and end in a GPU memory fault instead of the reference's
+        device-mismatch error; ``t`` must cover the batch (the kernels read t[0..B))."""
+        if x.dim() != 4:
+            raise ValueError(f"x must be [B, T, L, C], got {tuple(x.shape)}")
         B, T, L, Cc = x.shape
         if Cc != self.in_dim or x_cond.shape != x.shape or tuple(x_cond_mask.shape) != (B, T, L):
             raise ValueError(f"shape mismatch: x {tuple(x.shape)}, x_cond {tuple(x_cond.shape)}, mask {tuple(x_cond_mask.shape)}")
         if y is not None and (not hasattr(self, "vec_in") or tuple(y.shape) != (B, self.dims.vec_in_dim)):
             raise ValueError("y given but the model has no vec_in, or y has the wrong shape")
+        for name, ten in (("x_cond", x_cond), ("x_cond_mask", x_cond_mask), ("y", y), ("t", t), ("out", out)):
+            if ten is not None and ten.device != x.device:
+                raise RuntimeError(f"Expected all tensors to be on the same device, but {name} is on {ten.device} and x is on {x.device}")
+        if not x.is_contiguous() or x.dtype != torch.float32:
+            raise ValueError("x must be a contiguous float32 tensor")
+        if t is not None and (tuple(t.shape) != (B,) or t.dtype != torch.float32 or not t.is_contiguous()):
+            raise ValueError(f"t must be a contiguous float32 tensor of shape ({B},), got {tuple(t.shape)} {t.dtype}")
+        if out is not None and (out.shape != x.shape or out.dtype != torch.float32 or not out.is_contiguous()):
+            raise ValueError("out must be a contiguous float32 tensor shaped like x")
         keep = [x_cond.float().contiguous(), x_cond_mask.to(torch.int64).contiguous()]
         if y is not None:
             keep.append(y.float().contiguous())
@@ -226,14 +273,25 @@ class LatentSIV3(nn.Module):
     def forward(self, x: Tensor, t: Tensor, x_cond: Tensor, x_cond_mask: Tensor, y: Tensor = None) -> Tensor:
         self._require_gpu(x)
         lib = _lib.load()
-        self.ensure_packed(x.device)
-        xin = x.float().contiguous()
-        tt = t.float().contiguous()
-        out = torch.empty_like(xin)
-        io, keep = self.make_io(xin, x_cond, x_cond_mask, y, tt, out)
-        ws = self.workspace(io.B, io.T, io.L, x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(lib.lsl_forward(self._handle, C.byref(io), ws.data_ptr(), ws.numel(), stream))
+        if x.dim() != 4:
+            raise ValueError(f"x must be [B, T, L, C], got {tuple(x.shape)}")
+        if t.device != x.device:
+            raise RuntimeError(f"Expected all tensors to be on the same device, but t is on {t.device} and x is on {x.device}")
+        B = x.shape[0]
+        tt = t.detach().float()
+        if tt.dim() == 0 or tuple(tt.shape) == (1,):  # the reference broadcasts a scalar time over the batch (mmdit.py:107)
+            tt = tt.reshape(1).expand(B)
+        if tuple(tt.shape) != (B,):
+            raise ValueError(f"t must have shape ({B},) (or be a scalar), got {tuple(t.shape)}")
+        tt = tt.contiguous()
+        with torch.cuda.device(x.device):
+            self.ensure_packed(x.device)
+            xin = x.detach().float().contiguous()
+            out = torch.empty_like(xin)
+            io, keep = self.make_io(xin, x_cond, x_cond_mask, y, tt, out)
+            ws = self.workspace(io.B, io.T, io.L, x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(lib.lsl_forward(self._handle, C.byref(io), ws.data_ptr(), ws.numel(), stream))
         self.last_path = "hip"
         del keep
         return out.to(x.dtype)

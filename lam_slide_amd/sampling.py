@@ -14,7 +14,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from .latent_si import LatentSIV3
-from .transport import Sampler, Transport
+from .transport import Sampler, Transport, as_transport, device_randn, mix_seed
 
 
 @torch.no_grad()
@@ -52,29 +52,47 @@ class SecondStageSampler:
                  sampling_method: str = "ODE", sampling_kwargs: Optional[Dict[str, Any]] = None,
                  encode: Optional[Callable] = None, decode: Optional[Callable] = None, seed: int = 0):
         self.backbone = backbone
-        self.si = transport
+        self.si = as_transport(transport)
         self.cond_idx = tuple(cond_idx)
         self.mask_cond_mean = mask_cond_mean
         self.sampling_method = sampling_method
         self.sampling_kwargs = dict(sampling_kwargs or {"sampling_method": "euler", "num_steps": 10})
         self.encode, self.decode = encode, decode
         self.seed = seed
+        self.calls = 0  # sampling calls made so far: call k draws its noise from stream mix_seed(seed, k)
         self.last_sampler: Optional[Sampler] = None
+
+    def reseed(self, seed: Optional[int] = None):
+        """Restart the noise streams: the next call is call 0 of ``seed`` (default: the current seed) again."""
+        if seed is not None:
+            self.seed = seed
+        self.calls = 0
+
+    def _next_call_seed(self) -> int:
+        s = mix_seed(self.seed, self.calls)
+        self.calls += 1
+        return s
 
     def forward(self, xt: Tensor, t: Tensor, **model_kwargs) -> Tensor:  # lightning_base.py:173-174
         return self.backbone(x=xt, t=t, **model_kwargs)
 
     @torch.no_grad()
     def sample_latents(self, latents: Tensor, y: Optional[Tensor] = None, init: Optional[Tensor] = None,
-                       elem_offset: int = 0, noise: Optional[Tensor] = None) -> Tensor:
+                       first_index: int = 0, noise: Optional[Tensor] = None) -> Tensor:
         """latents: stage-1 latents [B,T,L,C] of the conditioning window (other frames are ignored).
-        init: optional explicit initial noise (the reference draws ``torch.randn_like(x_cond)`` on the device,
-        lightning_base.py:231; fixed-seed parity needs the tensor itself)."""
+        init: optional explicit initial noise (fixed-noise parity needs the tensor itself).  Without it every call draws fresh noise,
+        like the reference's ``torch.randn_like(x_cond)`` per ``sample()`` (lightning_base.py:231) and ``randn`` per Euler-Maruyama step
+        (integrators.py:30): call k of this object uses the counter stream ``mix_seed(seed, k)`` for the initial state and for the
+        per-step noise, so K consecutive calls give K different samples; ``reseed()`` replays them.
+        first_index: global index of ``latents[0]`` when this rank holds rows [first_index, first_index + B) of a sharded batch; the
+        streams are indexed by GLOBAL element, so sharded and unsharded runs draw identical noise (every rank must have made the same
+        number of calls)."""
         x_cond, mask = setup_conditioning(latents, self.cond_idx, self.mask_cond_mean)
+        call_seed = self._next_call_seed()
+        elem_offset = int(first_index) * x_cond[0].numel()
         if init is None:
-            g = torch.Generator(device=latents.device).manual_seed(self.seed + elem_offset)
-            init = torch.randn(x_cond.shape, generator=g, device=latents.device, dtype=x_cond.dtype)
-        sampler = Sampler(self.si, seed=self.seed)
+            init = device_randn(x_cond.shape, x_cond.device, call_seed, elem_offset).to(x_cond.dtype)
+        sampler = Sampler(self.si, seed=call_seed)
         sampler.elem_offset = elem_offset
         kw = dict(self.sampling_kwargs)
         if self.sampling_method == "SDE" and noise is not None:
@@ -102,12 +120,12 @@ class SecondStageSampler:
         mk = {"x_cond": xc, "x_cond_mask": mask.unsqueeze(0).expand(K, *mask.shape).reshape(K * B, *mask.shape[1:]).contiguous()}
         if y is not None:
             mk["y"] = y.unsqueeze(0).expand(K, *y.shape).reshape(K * B, *y.shape[1:]).contiguous()
-        if inits is None:
-            g = torch.Generator(device=latents.device).manual_seed(self.seed)
-            init = torch.randn(xc.shape, generator=g, device=latents.device, dtype=xc.dtype)
+        call_seed = self._next_call_seed()
+        if inits is None:  # K * B fresh draws: the K samples of one conditioning differ, and so do consecutive calls
+            init = device_randn(xc.shape, xc.device, call_seed).to(xc.dtype)
         else:
             init = inits.reshape(K * B, *inits.shape[2:])
-        sampler = Sampler(self.si, seed=self.seed)
+        sampler = Sampler(self.si, seed=call_seed)
         fn = sampler.get_sample_fn(self.sampling_method, dict(self.sampling_kwargs))
         out = fn(init, self.forward, **mk)[-1]
         self.last_sampler = sampler
@@ -119,7 +137,7 @@ class SecondStageSampler:
         if self.encode is None or self.decode is None:
             raise RuntimeError("sample(batch) needs the frozen stage-1 encode/decode callables")
         latents = self.encode(batch)
-        final = self.sample_latents(latents, y=batch.get("y"))
+        final = self.sample_latents(latents, y=batch.get("y"), first_index=int(batch.get("first_index", 0)))
         B = final.shape[0]
         flat = final.reshape(B * final.shape[1], *final.shape[2:])
         ent = batch["entities"].reshape(B * batch["entities"].shape[1], *batch["entities"].shape[2:])
@@ -174,3 +192,67 @@ def sample_rollout(sample_positions: Callable[[Tensor], Tensor], cond_pos: Tenso
     positions = torch.cat(rollouts)
     positions[0] = cond
     return positions * scale + shift
+
+
+@torch.no_grad()
+def best_of_k_errors(drv: "SecondStageSampler", latents: Tensor, target_pos: Tensor, K: int, decode: Callable[[Tensor], Tensor],
+                     agent_mask: Optional[Tensor] = None, y: Optional[Tensor] = None, inits: Optional[Tensor] = None,
+                     num_runs: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    """The evaluation tail of the trajectory models on the device (second_stage/pedestrian.py:186-212, nba.py:205-225): K samples per
+    scene, decoded, future frames only, one row per real agent, best-of-K ADE / FDE.  The reference runs K sequential ``sample()``
+    calls (re-encoding the same batch each time) and stacks the results on the host side of the loop; here the K samples are one fused
+    call (``sample_latents_k``), one decode, and the reductions of :func:`min_ade_fde`, with no host round trip in between.
+
+    latents [B,T,L,C] stage-1 latents; target_pos [B, T - c1, A, D] true future positions; ``decode(latents [K*B,T,L,C]) ->
+    positions [K*B, T, A, D]``; agent_mask [B, A] bool (``attention_mask[:, -1]``) or None.  Returns (ADE, FDE) per real agent."""
+    B = latents.shape[0]
+    c1 = drv.cond_idx[1]
+    final = drv.sample_latents_k(latents, K, y=y, inits=inits)            # [K, B, T, L, C]
+    pos = decode(final.reshape(K * B, *final.shape[2:]))                   # [K*B, T, A, D]
+    pos = pos.reshape(K, B, *pos.shape[1:])[:, :, c1:]                     # future frames
+    traj = pos.permute(1, 3, 0, 2, 4).reshape(B * pos.shape[3], K, pos.shape[2], pos.shape[4])   # "(B A) K T D"
+    tgt = target_pos.permute(0, 2, 1, 3).reshape(B * target_pos.shape[2], target_pos.shape[1], target_pos.shape[3])
+    if agent_mask is not None:
+        keep = agent_mask.reshape(-1).bool()
+        traj, tgt = traj[keep], tgt[keep]
+    if num_runs is not None:
+        traj = traj[:, :num_runs]
+    return min_ade_fde(traj, tgt)
+
+
+class RolloutSampler:
+    """Counterpart of ``SIAtom14SamplingWrapper`` (modules/sampling.py:16-63) for the tensors it handles: ``create_batch`` builds the
+    one-system batch whose every frame repeats the conditioning frame, ``sample_rollout`` chains ``num_rollouts`` samples, each
+    conditioned on the last frame of the previous one.  ``model`` is anything with ``sample(batch) -> {"atom14_pos": [1*T, R, A, D] or
+    [1, T, R, A, D]}``, ``shift``, ``scale`` and ``hparams.n_timesteps`` (or ``n_timesteps``) - the reference's peptide LightningModule,
+    or a :class:`SecondStageSampler` wired with device encode / decode.  Everything stays on ``cond_pos``'s device; the mdtraj
+    conversion (``sample_traj``) stays the reference's."""
+
+    def __init__(self, model, key: str = "atom14_pos"):
+        self.model = model
+        self.key = key
+
+    def _T(self) -> int:
+        hp = getattr(self.model, "hparams", None)
+        if hp is not None and hasattr(hp, "n_timesteps"):
+            return int(hp.n_timesteps)
+        return int(self.model.n_timesteps)
+
+    def create_batch(self, pos: Tensor, res: Tensor, res_mask: Tensor) -> Dict[str, Tensor]:
+        T = self._T()
+        pos = pos * res_mask[..., None].to(pos.device)
+        R = res.shape[0]
+        return {
+            self.key: pos[None, None].expand(1, T, *pos.shape),
+            "aatype": res[None, None].expand(1, T, R),
+            "attention_mask": torch.ones(1, T, R, dtype=torch.bool, device=res.device),
+            "entities": torch.arange(R, device=res.device).expand(T, -1).unsqueeze(0),
+        }
+
+    @torch.no_grad()
+    def sample_rollout(self, cond_pos: Tensor, res: Tensor, res_mask: Tensor, num_rollouts: int = 1) -> Tensor:
+        def one(pos):
+            out = self.model.sample(self.create_batch(pos=pos, res=res, res_mask=res_mask))[self.key]
+            return out.squeeze(0) if out.dim() == cond_pos.dim() + 2 else out
+
+        return sample_rollout(one, cond_pos, num_rollouts, shift=self.model.shift, scale=self.model.scale)

@@ -159,6 +159,8 @@ class CreateTransport:
     """Same keywords as the reference factory (transport/__init__.py:7-77); call it to get the Transport."""
 
     def __init__(self, path_type="Linear", prediction="velocity", loss_weight=None, train_eps=None, sample_eps=None):
+        from . import dropin
+        dropin.install()  # no-op unless a reference checkout's sampler modules are already imported (dropin.py)
         self.path_type = path_type
         self.prediction = prediction
         self.loss_weight = loss_weight
@@ -179,6 +181,50 @@ class CreateTransport:
             train_eps = 0
             sample_eps = 0
         return Transport(model_type=model_type, path_type=path_type, loss_type=loss_type, train_eps=train_eps, sample_eps=sample_eps)
+
+
+def as_transport(obj) -> "Transport":
+    """Accept the reference's own ``Transport`` object (src/modules/transport/transport.py:40-58) wherever this module wants one: a
+    LightningModule built from the ORIGINAL ``transport._target_: src.modules.transport.CreateTransport`` hands ``Sampler`` such an
+    object.  It is read by duck typing - enum member NAMES of ``model_type`` / ``loss_type``, the class name of ``path_sampler``
+    (ICPlan / GVPCPlan / VPCPlan, path.py:21-206) - and restated as a :class:`Transport` with the same eps values."""
+    if isinstance(obj, Transport):
+        return obj
+    try:
+        model_type = ModelType[obj.model_type.name]
+        loss_type = WeightType[getattr(getattr(obj, "loss_type", None), "name", "NONE")]
+        if hasattr(obj, "path_type"):
+            path_type = PathType[obj.path_type.name]
+        else:
+            path_type = {"ICPlan": PathType.LINEAR, "GVPCPlan": PathType.GVP, "VPCPlan": PathType.VP}[type(obj.path_sampler).__name__]
+        return Transport(model_type=model_type, path_type=path_type, loss_type=loss_type, train_eps=obj.train_eps, sample_eps=obj.sample_eps)
+    except (AttributeError, KeyError) as e:
+        raise TypeError(f"cannot interpret {type(obj).__name__} as a stochastic-interpolant Transport: {e}") from None
+
+
+_MASK64 = (1 << 64) - 1
+
+
+def mix_seed(seed: int, index: int) -> int:
+    """splitmix64 of (seed, index): the seed of call number ``index`` of an object seeded with ``seed``."""
+    z = (int(seed) + 0x9E3779B97F4A7C15 * (int(index) + 1)) & _MASK64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK64
+    return z ^ (z >> 31)
+
+
+def device_randn(shape, device, seed: int, elem_offset: int = 0) -> Tensor:
+    """Standard-normal tensor from the library's counter stream (``lsl_randn``): element e of the result is global element
+    ``elem_offset + e`` of stream ``seed``, so a rank that holds rows [lo, hi) of a batch draws exactly rows [lo, hi) of the
+    unsharded draw.  Counterpart of ``torch.randn_like(x_cond)`` in lightning_base.py:231."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("device_randn draws on the GPU (HIP kernel); there is no CPU fallback")
+    with torch.cuda.device(device):
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+        _lib.check(_lib.load().lsl_randn(out.data_ptr(), out.numel(), int(seed) & _MASK64, int(elem_offset),
+                                         torch.cuda.current_stream(device).cuda_stream))
+    return out
 
 
 class SampleResult(Sequence):
@@ -208,17 +254,31 @@ class SampleResult(Sequence):
         return self.trace[i - self.offset]
 
 
+def _unwrap(mod):
+    """``torch.compile`` wraps a module in an ``OptimizedModule`` that keeps the original as ``_orig_mod`` (the reference compiles its
+    backbone when ``compile: True``, second_stage/md17.py:53-55).  The HIP path has nothing for a tracing compiler to do; the fused
+    loop looks through the wrapper instead of silently losing the native path."""
+    seen = 0
+    while mod is not None and not isinstance(mod, LatentSIV3) and hasattr(mod, "_orig_mod") and seen < 4:
+        mod = mod._orig_mod
+        seen += 1
+    return mod
+
+
 def resolve_backbone(model: Callable) -> Optional[LatentSIV3]:
+    model = _unwrap(model)
     if isinstance(model, LatentSIV3):
         return model
-    tagged = getattr(model, "lsl_backbone", None)
+    tagged = _unwrap(getattr(model, "lsl_backbone", None))
     if isinstance(tagged, LatentSIV3):
         return tagged
-    owner = getattr(model, "__self__", None)
+    owner = _unwrap(getattr(model, "__self__", None))
     if isinstance(owner, LatentSIV3) and getattr(model, "__name__", "") in ("forward", "__call__"):
         return owner
-    if owner is not None and getattr(model, "__name__", "") == "forward" and isinstance(getattr(owner, "backbone", None), LatentSIV3):
-        return owner.backbone  # LightningModule.forward == backbone(x=xt, t=t, **kw) (lightning_base.py:173-174)
+    if owner is not None and getattr(model, "__name__", "") == "forward":
+        inner = _unwrap(getattr(owner, "backbone", None))
+        if isinstance(inner, LatentSIV3):
+            return inner  # LightningModule.forward == backbone(x=xt, t=t, **kw) (lightning_base.py:173-174)
     return None
 
 
@@ -227,13 +287,30 @@ def _f32(v: float) -> float:
 
 
 class Sampler:
-    def __init__(self, transport: Transport, fused: Optional[bool] = None, keep_trajectory: bool = False, seed: int = 0):
-        self.transport = transport
+    """``Sampler(transport)`` as in the reference (transport.py:229-244; rebuilt on every ``sample()`` call, lightning_base.py:219).
+
+    Device noise (Euler-Maruyama steps without an explicit ``noise=`` tensor): every sampling CALL draws from a stream of its own, as
+    the reference draws fresh ``randn`` per step and per call (integrators.py:30).  ``seed=None`` (default): the call's stream seed
+    comes from torch's global generator, so ``torch.manual_seed`` / ``seed_everything`` make a run reproducible and consecutive calls
+    differ.  ``seed=int``: call number k of this object uses ``mix_seed(seed, k)`` - reproducible by rebuilding the Sampler with the
+    same seed."""
+
+    def __init__(self, transport: Transport, fused: Optional[bool] = None, keep_trajectory: bool = False, seed: Optional[int] = None):
+        self.transport = as_transport(transport)
         self.fused = fused
         self.keep_trajectory = keep_trajectory
         self.seed = seed
+        self.calls = 0
+        self.last_seed: Optional[int] = None  # stream seed of the most recent fused call
         self.last_path: Optional[str] = None
         self.elem_offset = 0  # global element index of this rank's first state element (device noise stream)
+
+    def next_call_seed(self) -> int:
+        k = self.calls
+        self.calls += 1
+        if self.seed is None:
+            return int(torch.randint(0, 1 << 62, (1,)).item())
+        return mix_seed(self.seed, k)
 
     # ---- step tables ------------------------------------------------------------------------------------
     def ode_steps(self, num_steps: int, reverse: bool = False) -> Tuple[List[Tuple[float, float, float, float]], Tensor]:
@@ -298,34 +375,47 @@ class Sampler:
             raise TypeError(f"unexpected model kwargs {sorted(extra)}")
         net._require_gpu(init)
         lib = _lib.load()
-        net.ensure_packed(init.device)
-        # state and conditioning live in per-shape persistent buffers of the model (stable pointers -> hipGraph replay in lsl_sample)
-        x = net.pinned("state", init.detach(), torch.float32)
-        xc = net.pinned("x_cond", model_kwargs["x_cond"].detach(), torch.float32)
-        xm = net.pinned("x_cond_mask", model_kwargs["x_cond_mask"].detach(), torch.int64)
-        yv = model_kwargs.get("y")
-        if yv is not None:
-            yv = net.pinned("y", yv.detach(), torch.float32)
-        io, keep = net.make_io(x, xc, xm, yv)
-        ws = net.workspace(io.B, io.T, io.L, init.device)
-        arr = (_lib.Step * len(steps))(*[_lib.Step(*s) for s in steps])
-        trace = None
-        if self.keep_trajectory:
-            trace = torch.empty((len(steps),) + tuple(x.shape), dtype=torch.float32, device=x.device)
-        nz = None
-        if noise is not None:  # slice s belongs to step s, like the reference's one draw per EM step
-            nz = noise.detach().float().contiguous().to(x.device)
-            need = max([i + 1 for i, s in enumerate(steps) if s[3] != 0.0], default=0)
-            if nz.shape[0] < need or tuple(nz.shape[1:]) != tuple(x.shape):
-                raise ValueError(f"noise must be [>={need}, {tuple(x.shape)}], got {tuple(nz.shape)}")
-        stream = torch.cuda.current_stream(init.device).cuda_stream
-        _lib.check(lib.lsl_sample(net._handle, C.byref(io), arr, len(steps), nz.data_ptr() if nz is not None else None,
-                                  nz.shape[0] if nz is not None else 0, self.seed, self.elem_offset, trace.data_ptr() if trace is not None else None, ws.data_ptr(),
-                                  ws.numel(), stream))
+        dev = init.device
+        for name in ("x_cond", "x_cond_mask"):
+            if name not in model_kwargs:
+                raise TypeError(f"missing model kwarg {name!r}")
+        for name, ten in model_kwargs.items():
+            if ten is not None and ten.device != dev:
+                raise RuntimeError(f"Expected all tensors to be on the same device, but {name} is on {ten.device} and the state is on {dev}")
+        call_seed = self.next_call_seed()
+        self.last_seed = call_seed
+        with torch.cuda.device(dev):
+            net.ensure_packed(dev)
+            # the state is updated in place by the library: always a private copy (persistent buffers only under LSL_GRAPH, see staged())
+            x = net.staged("state", init, torch.float32, dev, fresh=True)
+            xc = net.staged("x_cond", model_kwargs["x_cond"], torch.float32, dev)
+            xm = net.staged("x_cond_mask", model_kwargs["x_cond_mask"], torch.int64, dev)
+            yv = model_kwargs.get("y")
+            if yv is not None:
+                yv = net.staged("y", yv, torch.float32, dev)
+            io, keep = net.make_io(x, xc, xm, yv)
+            ws = net.workspace(io.B, io.T, io.L, dev)
+            arr = (_lib.Step * len(steps))(*[_lib.Step(*s) for s in steps])
+            trace = None
+            if self.keep_trajectory:
+                trace = torch.empty((len(steps),) + tuple(x.shape), dtype=torch.float32, device=dev)
+            nz = None
+            if noise is not None:  # slice s belongs to step s, like the reference's one draw per EM step
+                nz = noise.detach().float().contiguous().to(dev)
+                need = max([i + 1 for i, s in enumerate(steps) if s[3] != 0.0], default=0)
+                if nz.shape[0] < need or tuple(nz.shape[1:]) != tuple(x.shape):
+                    raise ValueError(f"noise must be [>={need}, {tuple(x.shape)}], got {tuple(nz.shape)}")
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.lsl_sample(net._handle, C.byref(io), arr, len(steps), nz.data_ptr() if nz is not None else None,
+                                      nz.shape[0] if nz is not None else 0, call_seed, self.elem_offset,
+                                      trace.data_ptr() if trace is not None else None, ws.data_ptr(), ws.numel(), stream))
         net.last_path = "hip"
         self.last_path = "fused"
         del keep
-        x = x.clone() if x.dtype == init.dtype else x.to(init.dtype)  # the persistent buffer is overwritten by the next call
+        if net.graph_replay_enabled():
+            x = x.clone()  # the persistent buffer is overwritten by the next call
+        if x.dtype != init.dtype:
+            x = x.to(init.dtype)
         if trace is None:
             return SampleResult(x, n_result)
         if duplicate_last:  # last_step=None: the reference appends xs[-1] again (transport.py:353-357)

@@ -60,3 +60,11 @@ def shape_from(d):
 
 def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def parity(name: str, err: float, bar: float) -> float:
+    """Assert ``err < bar`` and leave a greppable record ("PARITY name measured bar") in the log: the bars of the GPU tests are set to
+    about 5x the value measured on MI355X, so a kernel regression that multiplies an error shows up instead of hiding under 1e-3."""
+    print(f"PARITY {name} measured {err:.3e} bar {bar:.1e}")
+    assert err < bar, (name, err, bar)
+    return err

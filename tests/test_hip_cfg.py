@@ -1,0 +1,238 @@
+"""GPU parity at the BASELINE.json configurations themselves and of the evaluation steps next to the path:
+  * cfg 2 (the headline): T=30, L=256, C=32, D=512, H=16, depth 4, 50 Euler updates, through SecondStageSampler + Stage1Decoder against
+    the oracle chain; B=32 (the 960-tile persistent regime of the bench) bit-equal to B=1;
+  * cfg 4 family: a 250-step Euler-Maruyama run with stored noise (error growth over a long stochastic solve);
+  * f4: best-of-K ADE/FDE on decoded K-sample output and chained rollouts through the real encode -> sample -> decode closure;
+  * noise: consecutive calls differ, reseed() replays, sharded == unsharded without explicit noise.
+Bars are ~5x the values measured on MI355X (conftest.parity prints both)."""
+import pytest
+import torch
+
+from conftest import parity, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _net(kw, seed, dev):
+    from lam_slide_amd import LatentSIV3
+    from oracle import latent_net
+    sh = latent_net.NetShape(**kw)
+    p = latent_net.random_params(sh, seed=seed)
+    net = LatentSIV3(reset_parameters=False, **kw)
+    net.load_state_dict(p)
+    return net.to(dev), sh, p
+
+
+def test_cfg2_md17_bench_full(dev):
+    """BASELINE configs[1] as benchmarked: 7680 tokens per trajectory, D=512 (K=512 / 1536 GEMMs, head_dim 32, S=256 spatial and S=30
+    temporal attention), num_steps=51 = 50 state updates.  B=2 against the CPU oracle, latents and decoded coordinates."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler, Stage1Decoder
+    from lam_slide_amd.synthetic import seeded_decoder_state_dict
+    from oracle import harness, transport as otr
+    kw = dict(depth=4, in_dim=32, hidden_size=512, num_heads=16, mlp_ratio=2)
+    net, sh, p = _net(kw, 0, dev)
+    B, T, L = 2, 30, 256
+    g = torch.Generator().manual_seed(1)
+    lat, init = torch.randn(B, T, L, 32, generator=g), torch.randn(B, T, L, 32, generator=g)
+    skw = {"sampling_method": "euler", "num_steps": 51}
+    dsd = seeded_decoder_state_dict(seed=7)
+    dec = Stage1Decoder(dsd, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+    drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, 10), mask_cond_mean=True, sampling_kwargs=skw, decode=dec)
+    got = drv.sample_latents(lat.to(dev), init=init.to(dev))
+    assert drv.last_sampler.last_path == "fused" and net.last_path == "hip"
+    ent = torch.arange(21)[None].expand(B * T, 21)
+    pos = dec.decode(got.reshape(B * T, L, 32), ent.to(dev)).cpu()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    xc, m = harness.setup_conditioning(lat, (0, 10), True)
+    want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, m, None, "ODE", skw)
+    pos_want = harness.decode(dsd, harness.DecoderShape(), want.reshape(B * T, L, 32), ent)
+    parity("cfg2.latents", rel_l2(got.cpu(), want), 3e-4)
+    parity("cfg2.decoded_coords", rel_l2(pos, pos_want), 2e-4)
+
+
+def test_cfg2_batch32_equals_batch1_bits(dev):
+    """The bench runs 32 trajectories per pass (960 token tiles, persistent GEMM workgroups walking several tiles each); a trajectory's
+    bits must not depend on that: B=32 against the same trajectories sampled alone (30 tiles, one round of the grid)."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler
+    kw = dict(depth=4, in_dim=32, hidden_size=512, num_heads=16, mlp_ratio=2)
+    net, _, _ = _net(kw, 0, dev)
+    B, T, L = 32, 30, 256
+    g = torch.Generator().manual_seed(5)
+    lat, init = torch.randn(B, T, L, 32, generator=g).to(dev), torch.randn(B, T, L, 32, generator=g).to(dev)
+    drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, 10), sampling_kwargs={"sampling_method": "euler", "num_steps": 6})
+    full = drv.sample_latents(lat, init=init)
+    assert torch.isfinite(full).all()
+    for i in (0, 17, 31):
+        assert torch.equal(full[i:i + 1], drv.sample_latents(lat[i:i + 1], init=init[i:i + 1])), i
+
+
+def test_long_sde_250_steps_with_stored_noise(dev):
+    """Peptide family (D=384, head_dim 24 padded to 32, C=96, depth 7, L=2) at T=64: 250-step Euler-Maruyama, linear diffusion, "Mean"
+    last step, every noise slice stored; the drift gain (pi/2)/cos(pi t/2) and 250 accumulated bf16-operand evaluations are where an
+    error would grow.  Final and mid-trajectory states against the oracle (one evaluation per step on both sides)."""
+    from lam_slide_amd import CreateTransport, Sampler
+    from oracle import harness, transport as otr
+    kw = dict(depth=7, in_dim=96, hidden_size=384, num_heads=16, mlp_ratio=4)
+    net, sh, p = _net(kw, 11, dev)
+    B, T, L, n = 1, 64, 2, 250
+    g = torch.Generator().manual_seed(8)
+    lat, init = torch.randn(B, T, L, 96, generator=g), torch.randn(B, T, L, 96, generator=g)
+    noise = torch.randn(n - 1, B, T, L, 96, generator=g)
+    xc, m = harness.setup_conditioning(lat, (0, 1), True)
+    s = Sampler(CreateTransport("GVP", "data")(), fused=True, keep_trajectory=True)
+    res = s.sample_sde(diffusion_form="linear", last_step="Mean", num_steps=n, noise=noise.to(dev))(init.to(dev), net.forward, x_cond=xc.to(dev),
+                                                                                                     x_cond_mask=m.to(dev))
+    assert s.last_path == "fused" and len(res) == n
+    states = {}
+
+    def model(xt, t, **kw_):
+        from oracle import latent_net
+        return latent_net.forward(p, sh, xt, t.to(xt.dtype), **kw_)
+
+    xs = otr.sample_sde(otr.Transport("GVP", "data"), init, model, noise=list(noise), diffusion_form="linear", last_step="Mean", num_steps=n,
+                        single_eval=True, x_cond=xc, x_cond_mask=m)
+    assert len(xs) == n
+    for i, tag in ((n // 2, "mid"), (n - 2, "penultimate"), (n - 1, "final")):
+        states[tag] = rel_l2(res[i].cpu(), xs[i])
+    parity("sde250.mid", states["mid"], 1e-3)
+    parity("sde250.penultimate", states["penultimate"], 1e-3)
+    parity("sde250.final", states["final"], 1e-3)
+
+
+def _pedestrian_chain(dev, B=4, K=20):
+    from lam_slide_amd import CreateTransport, SecondStageSampler, Stage1Decoder, Stage1Encoder
+    from conftest import Fixture
+    e, d = Fixture("f7_encode.npz"), Fixture("f6_decode.npz")
+    enc = Stage1Encoder(e.group("p"), num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16)
+    dec = Stage1Decoder(d.group("p"), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+    kw = dict(depth=6, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2, vec_in_dim=256, normalize=True)
+    net, sh, p = _net(kw, 17, dev)
+    drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, 8), mask_cond_mean=True,
+                             sampling_kwargs={"sampling_method": "euler", "num_steps": 11})
+    return enc, dec, net, sh, p, drv, e.group("p"), d.group("p")
+
+
+def test_best_of_k_errors_on_device_against_the_oracle_chain(dev):
+    """f4(i): pedestrian shape (T=20, D=128, class vector, normalize), K=20 samples per scene folded into one fused call, decoded on the
+    device, best-of-K ADE/FDE reduced on the device - against K sequential oracle samples + oracle decode + the reference formula."""
+    from lam_slide_amd import best_of_k_errors
+    from oracle import harness, transport as otr
+    enc, dec, net, sh, p, drv, ep, dp = _pedestrian_chain(dev)
+    B, T, L, A, K = 3, 20, 48, 10, 20
+    g = torch.Generator().manual_seed(23)
+    lat = torch.randn(B, T, L, 32, generator=g)
+    y = torch.randn(B, 256, generator=g)
+    inits = torch.randn(K, B, T, L, 32, generator=g)
+    ent = torch.stack([torch.randperm(32, generator=g)[:A] for _ in range(B)])         # entity ids of a scene, same on all frames
+    target = torch.randn(B, T - 8, A, 3, generator=g)
+    amask = torch.rand(B, A, generator=g) > 0.2
+
+    def decode_dev(z):  # [K*B, T, L, C] -> [K*B, T, A, 3]
+        n = z.shape[0]
+        e_ = ent.to(dev).repeat(K, 1)[:n].repeat_interleave(T, dim=0)
+        return dec.decode(z.reshape(n * T, L, 32), e_).reshape(n, T, A, 3)
+
+    ade, fde = best_of_k_errors(drv, lat.to(dev), target.to(dev), K, decode_dev, agent_mask=amask.to(dev), y=y.to(dev), inits=inits.to(dev))
+    assert ade.is_cuda and drv.last_sampler.last_path == "fused"
+    xc, m = harness.setup_conditioning(lat, (0, 8), True)
+    per_k = []
+    for k in range(K):  # the reference's loop: one sample() per k
+        fin = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), inits[k], xc, m, y, "ODE", {"sampling_method": "euler", "num_steps": 11})
+        pos = harness.decode(dp, harness.DecoderShape(), fin.reshape(B * T, L, 32), ent.repeat_interleave(T, dim=0)).reshape(B, T, A, 3)
+        per_k.append(pos[:, 8:].permute(0, 2, 1, 3).reshape(B * A, T - 8, 3)[amask.reshape(-1)])
+    want_a, want_f = harness.compute_errors(torch.stack(per_k, dim=1), target.permute(0, 2, 1, 3).reshape(B * A, T - 8, 3)[amask.reshape(-1)])
+    parity("f4.best_of_k.ade", rel_l2(ade.cpu(), want_a), 1e-3)
+    parity("f4.best_of_k.fde", rel_l2(fde.cpu(), want_f), 1e-3)
+
+
+def test_rollouts_through_the_real_closure_on_device(dev):
+    """f4(ii): three chained rollouts (modules/sampling.py:44-63); each rollout = encode the conditioning frame repeated over T ->
+    setup_conditioning -> fused sampler -> decode, all on the device with no host copy between rollouts, against the same chain on the
+    oracle with the same initial noises."""
+    from lam_slide_amd import sample_rollout
+    from oracle import harness, transport as otr
+    enc, dec, net, sh, p, drv, ep, dp = _pedestrian_chain(dev)
+    T, A, R = 20, 12, 3
+    g = torch.Generator().manual_seed(29)
+    feat = torch.randn(3, 128, generator=g)   # stands for the dataset-specific prepare_inputs: positions -> encoder input
+    ent = torch.randperm(32, generator=g)[:A]
+    y = torch.randn(1, 256, generator=g)
+    inits = torch.randn(R, 1, T, 48, 32, generator=g)
+    cond = torch.randn(A, 3, generator=g) * 2.0 + 1.5
+    shift, scale = 1.5, 2.0
+    calls = {"n": 0}
+
+    def sample_positions_dev(pos):  # pos [A, 3] on the device -> [T, A, 3]
+        assert pos.is_cuda
+        x = (pos @ feat.to(dev))[None].expand(T, A, 128).contiguous()
+        z = enc.encode(x, ent.to(dev)[None].expand(T, A).contiguous(), torch.ones(T, A, dtype=torch.bool, device=dev))
+        fin = drv.sample_latents(z[None], y=y.to(dev), init=inits[calls["n"]].to(dev))
+        calls["n"] += 1
+        return dec.decode(fin[0], ent.to(dev)[None].expand(T, A).contiguous())
+
+    out = sample_rollout(sample_positions_dev, cond.to(dev), num_rollouts=R, shift=shift, scale=scale)
+    assert out.is_cuda and out.shape == (R * T, A, 3) and calls["n"] == R
+    k = {"n": 0}
+
+    def sample_positions_cpu(pos):
+        x = (pos @ feat)[None].expand(T, A, 128)
+        z = harness.encode(ep, harness.EncoderShape(num_latents=48), x, ent[None].expand(T, A), torch.ones(T, A, dtype=torch.bool))
+        xc, m = harness.setup_conditioning(z[None], (0, 8), True)
+        fin = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), inits[k["n"]], xc, m, y, "ODE", {"sampling_method": "euler", "num_steps": 11})
+        k["n"] += 1
+        return harness.decode(dp, harness.DecoderShape(), fin[0], ent[None].expand(T, A))
+
+    want = sample_rollout(sample_positions_cpu, cond, num_rollouts=R, shift=shift, scale=scale)
+    assert torch.equal(out[0].cpu(), cond)
+    parity("f4.rollout.first", rel_l2(out[:T].cpu(), want[:T]), 1e-3)
+    parity("f4.rollout.third", rel_l2(out[2 * T:].cpu(), want[2 * T:]), 3e-3)   # errors chain through the conditioning frame
+
+
+def test_fresh_noise_per_call_and_shard_invariance(dev):
+    """without explicit noise every sampling call must draw fresh noise (K calls -> K different samples), reseed() replays, and
+    a rank holding rows [lo, hi) of a batch draws exactly the rows of the unsharded call (initial state AND per-step SDE noise)."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler, device_randn
+    kw = dict(depth=1, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2)
+    net, _, _ = _net(kw, 4, dev)
+    lat = torch.randn(4, 8, 16, 32, generator=torch.Generator().manual_seed(0)).to(dev)
+    for method, skw in (("ODE", {"sampling_method": "euler", "num_steps": 4}), ("SDE", {"num_steps": 4})):
+        drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, 2), sampling_method=method, sampling_kwargs=skw, seed=9)
+        a, b = drv.sample_latents(lat), drv.sample_latents(lat)
+        assert not torch.equal(a, b), method
+        drv.reseed()
+        assert torch.equal(a, drv.sample_latents(lat)) and torch.equal(b, drv.sample_latents(lat))
+        drv.reseed()
+        parts = []
+        for lo, hi in ((0, 1), (1, 4)):           # every "rank" makes the same number of calls
+            drv.reseed()
+            parts.append(drv.sample_latents(lat[lo:hi], first_index=lo))
+        assert torch.equal(a, torch.cat(parts)), method
+        k1 = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, 2), sampling_method=method, sampling_kwargs=skw, seed=9)
+        ks = k1.sample_latents_k(lat, 3)
+        assert not torch.equal(ks[0], ks[1]) and not torch.equal(ks[1], ks[2])
+    r = device_randn((1 << 18,), dev, 3)
+    assert abs(float(r.mean())) < 0.01 and abs(float(r.std()) - 1) < 0.01
+    assert torch.equal(device_randn((100,), dev, 3, elem_offset=50), r[50:150])
+
+
+def test_forward_argument_checks_on_device(dev):
+    """a scalar / [1] time broadcasts like the reference; a tensor on another device raises instead of faulting the GPU."""
+    kw = dict(depth=1, in_dim=8, hidden_size=64, num_heads=4)
+    net, _, _ = _net(kw, 2, dev)
+    g = torch.Generator().manual_seed(0)
+    x, xc = torch.randn(3, 4, 5, 8, generator=g).to(dev), torch.randn(3, 4, 5, 8, generator=g).to(dev)
+    m = torch.zeros(3, 4, 5, dtype=torch.long, device=dev)
+    full = net(x, torch.full((3,), 0.3, device=dev), xc, m)
+    assert torch.equal(full, net(x, torch.tensor(0.3, device=dev), xc, m)) and torch.equal(full, net(x, torch.tensor([0.3], device=dev), xc, m))
+    with pytest.raises(RuntimeError):
+        net(x, torch.full((3,), 0.3), xc, m)
+    with pytest.raises(RuntimeError):
+        net(x, torch.full((3,), 0.3, device=dev), xc.cpu(), m)
+    with pytest.raises(ValueError):
+        net(x, torch.full((2,), 0.3, device=dev), xc, m)

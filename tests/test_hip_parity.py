@@ -13,7 +13,7 @@ import ctypes as C
 import pytest
 import torch
 
-from conftest import rel_l2, shape_from
+from conftest import parity, rel_l2, shape_from
 
 pytestmark = pytest.mark.gpu
 
@@ -61,10 +61,10 @@ def test_conditioning_vector_and_modulation_fp32(golden, dev):
                                   ws.numel(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     taps = f.group("taps")
-    assert rel_l2(vec.cpu(), taps["vec"]) < 2e-5
+    parity("f1.vec", rel_l2(vec.cpu(), taps["vec"]), 5e-6)
     for i in range(sh.depth):
-        assert rel_l2(mods[:, 6 * D * i:6 * D * (i + 1)].cpu(), taps[f"l{i}.mod"]) < 2e-5
-    assert rel_l2(mods[:, 6 * D * sh.depth:].cpu(), taps["final_mod"].reshape(B, 2 * D)) < 2e-5
+        parity(f"f1.mod{i}", rel_l2(mods[:, 6 * D * i:6 * D * (i + 1)].cpu(), taps[f"l{i}.mod"]), 5e-6)
+    parity("f1.final_mod", rel_l2(mods[:, 6 * D * sh.depth:].cpu(), taps["final_mod"].reshape(B, 2 * D)), 5e-6)
 
 
 def test_each_block_against_reference_intermediates(golden, dev):
@@ -94,7 +94,7 @@ def test_each_block_against_reference_intermediates(golden, dev):
                                            ws.numel(), torch.cuda.current_stream().cuda_stream))
             torch.cuda.synchronize()
             upd, want = o.cpu() - hin, hout - hin
-            assert rel_l2(upd, want) < 1e-2, (bi, rel_l2(upd, want))
+            parity(f"f1.block{bi}.update", rel_l2(upd, want), 1e-2)
         h_prev = h_end
 
 
@@ -104,7 +104,7 @@ def test_forward_f1(golden, dev):
     net = build_net(sh, f.group("p"), dev)
     out = net(f["x"].to(dev), f["t"].to(dev), f["x_cond"].to(dev), f["mask"].to(dev), f["y"].to(dev))
     assert net.last_path == "hip"
-    assert rel_l2(out.cpu(), f.group("taps")["out"]) < 5e-3
+    parity("f1.forward", rel_l2(out.cpu(), f.group("taps")["out"]), 5e-3)
 
 
 def test_forward_shape_classes(golden, dev):
@@ -119,8 +119,7 @@ def test_forward_shape_classes(golden, dev):
         net = build_net(sh, p, dev)
         y = g.get("y")
         out = net(g["x"].to(dev), g["t"].to(dev), g["x_cond"].to(dev), g["mask"].to(dev), y.to(dev) if y is not None else None)
-        err = rel_l2(out.cpu(), g["out"])
-        assert err < 5e-3, (n, err)
+        parity(f"f2.{n}", rel_l2(out.cpu(), g["out"]), 5e-3)
 
 
 def _sampler(net, path="GVP", pred="data", **kw):
@@ -137,13 +136,11 @@ def test_ode_samplers_against_reference_outputs(golden, dev):
         s = _sampler(net)
         res = s.get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": n})(init, net.forward, x_cond=xc, x_cond_mask=mask)
         assert s.last_path == "fused" and len(res) == n
-        err = rel_l2(res[-1].cpu(), f[f"ode{n}"])
-        assert err < 3e-3, (n, err)
+        parity(f"f4.ode{n}", rel_l2(res[-1].cpu(), f[f"ode{n}"]), 3e-3)
     for path, pred in (("Linear", "velocity"), ("Linear", "data"), ("VP", "noise"), ("GVP", "score")):
         s = _sampler(net, path, pred)
         res = s.get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": 6})(init, net, x_cond=xc, x_cond_mask=mask)
-        err = rel_l2(res[-1].cpu(), f[f"ode6.{path}.{pred}"])
-        assert err < 3e-3, (path, pred, err)
+        parity(f"f4.ode6.{path}.{pred}", rel_l2(res[-1].cpu(), f[f"ode6.{path}.{pred}"]), 3e-3)
 
 
 def test_sde_samplers_with_stored_noise(golden, dev):
@@ -157,15 +154,15 @@ def test_sde_samplers_with_stored_noise(golden, dev):
         fn = s.sample_sde(sampling_method="Euler", diffusion_form=form, last_step=last, num_steps=n, noise=f[tag + ".noise"].to(dev))
         res = fn(init, net.forward, x_cond=xc, x_cond_mask=mask)
         assert s.last_path == "fused" and len(res) == n
-        assert rel_l2(res[-1].cpu(), f[tag + ".final"]) < 3e-3, tag
-        assert rel_l2(res[-2].cpu(), f[tag + ".penultimate"]) < 3e-3, tag
+        parity(f"f4.{tag}.final", rel_l2(res[-1].cpu(), f[tag + ".final"]), 3e-3)
+        parity(f"f4.{tag}.penultimate", rel_l2(res[-2].cpu(), f[tag + ".penultimate"]), 3e-3)
     # Heun goes through the generic loop (network still on the HIP path)
     tag = "sde5.linear.Mean.Heun"
     s = _sampler(net)
     fn = s.sample_sde(sampling_method="Heun", diffusion_form="linear", last_step="Mean", num_steps=5, noise=f[tag + ".noise"].to(dev))
     res = fn(init, net.forward, x_cond=xc, x_cond_mask=mask)
     assert s.last_path == "generic" and net.last_path == "hip" and len(res) == 5
-    assert rel_l2(res[-1].cpu(), f[tag + ".final"]) < 3e-3
+    parity(f"f4.{tag}.final", rel_l2(res[-1].cpu(), f[tag + ".final"]), 3e-3)
 
 
 def test_cfg1_decoded_coordinates(golden, dev):
@@ -190,9 +187,8 @@ def test_cfg1_decoded_coordinates(golden, dev):
     pos_got = harness.decode(d.group("p"), harness.DecoderShape(), got[0], ent)
     pos_want = harness.decode(d.group("p"), harness.DecoderShape(), want[0], ent)
     pos_err = rel_l2(pos_got, pos_want)
-    print(f"cfg1: latents rel L2 {lat_err:.3e}, decoded coordinates rel L2 {pos_err:.3e}")
-    assert lat_err < 3e-3
-    assert pos_err < 1e-3
+    parity("cfg1.latents", lat_err, 3e-3)
+    parity("cfg1.decoded_coords", pos_err, 1e-3)
 
 
 def test_batch_independence_and_chunking_bit_exact(dev):
@@ -307,9 +303,7 @@ def test_baseline_config_shapes(name, dev):
         got = s.get_sample_fn("ODE", skw)(init.to(dev), net.forward, **mk)[-1]
         want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, mask, y, "ODE", skw)
     assert s.last_path == "fused"
-    err = rel_l2(got.cpu(), want)
-    print(f"{name}: final latents rel L2 {err:.3e}")
-    assert err < 3e-3, (name, err)
+    parity(f"config.{name}.latents", rel_l2(got.cpu(), want), 3e-3)
 
 
 def test_k_sample_batching_equals_sequential_calls(dev):
@@ -337,9 +331,7 @@ def test_stage1_decode_against_reference_positions(golden, dev):
     d = golden("f6_decode.npz")
     dec = Stage1Decoder(d.group("p"), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16, act="gelu_erf")
     pos = dec.decode(d["z"].to(dev), d["entities"].to(dev)).cpu()
-    err = rel_l2(pos, d["pos"])
-    print(f"stage-1 decode rel L2 {err:.3e}")
-    assert err < 1e-5
+    parity("f6.decode", rel_l2(pos, d["pos"]), 1e-5)
     # frames are independent: any subset decodes to the same bits
     part = dec.decode(d["z"][1:3].to(dev), d["entities"][1:3].to(dev)).cpu()
     assert torch.equal(part, pos[1:3])
@@ -365,9 +357,7 @@ def test_sample_then_decode_on_device(golden, dev):
     ent = torch.arange(21)[None].expand(30, 21)
     pos = dec.decode(final[0], ent.to(dev)).cpu()
     want = harness.decode(d.group("p"), harness.DecoderShape(), f["final"][0], ent)
-    err = rel_l2(pos, want)
-    print(f"sample + decode on device: decoded coordinates rel L2 {err:.3e}")
-    assert err < 1e-3
+    parity("cfg1.sample_decode_on_device", rel_l2(pos, want), 1e-3)
 
 
 def test_stage1_encode_against_reference_latents(golden, dev):
@@ -377,9 +367,7 @@ def test_stage1_encode_against_reference_latents(golden, dev):
     d = golden("f7_encode.npz")
     enc = Stage1Encoder(d.group("p"), num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16, act="gelu_erf")
     z = enc.encode(d["x"].to(dev), d["entities"].to(dev), d["mask"].to(dev)).cpu()
-    err = rel_l2(z, d["z"])
-    print(f"stage-1 encode rel L2 {err:.3e}")
-    assert err < 1e-5
+    parity("f7.encode", rel_l2(z, d["z"]), 1e-5)
     part = enc.encode(d["x"][1:2].to(dev), d["entities"][1:2].to(dev), d["mask"][1:2].to(dev)).cpu()
     assert torch.equal(part, z[1:2])
     # masked-out entities do not influence the latents
@@ -397,9 +385,7 @@ def test_stage1_decode_query_splitter_cross_block_tanh(golden, dev):
     dec = Stage1Decoder(d.group("p"), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16, act="gelu_tanh")
     assert (dec.num_split, dec.num_block_cross) == (4, 1)
     pos = dec.decode(d["z"].to(dev), d["entities"].to(dev)).cpu()
-    err = rel_l2(pos, d["pos"])
-    print(f"stage-1 decode (query splitter) rel L2 {err:.3e}")
-    assert err < 1e-5
+    parity("f8.decode_split", rel_l2(pos, d["pos"]), 1e-5)
 
 
 RANDOM_SHAPES = {
@@ -431,10 +417,8 @@ def test_forward_edge_shapes_vs_oracle(name, dev):
     y = torch.randn(B, sh.vec_in_dim, generator=g) if sh.vec_in_dim else None
     want = latent_net.forward(p, sh, x, t, xc, mask, y)
     got = net(x.to(dev), t.to(dev), xc.to(dev), mask.to(dev), y.to(dev) if y is not None else None).cpu()
-    err = rel_l2(got, want)
-    print(f"{name}: rel L2 {err:.3e}")
     assert net.last_path == "hip" and torch.isfinite(got).all()
-    assert err < 5e-3, (name, err)
+    parity(f"edge.{name}", rel_l2(got, want), 5e-3)
 
 
 def test_full_chain_encode_sample_decode_on_device(golden, dev):
@@ -473,8 +457,9 @@ def test_full_chain_encode_sample_decode_on_device(golden, dev):
     final_o = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, m, None, "ODE", skw)
     pos_o = harness.decode(d.group("p"), harness.DecoderShape(), final_o.reshape(B * T, 48, 32), ent)
     err_lat, err_pos = rel_l2(final.cpu(), final_o), rel_l2(pos, pos_o)
-    print(f"full chain: encoded latents {rel_l2(lat.cpu(), lat_o):.2e}, sampled latents {err_lat:.2e}, decoded coordinates {err_pos:.2e}")
-    assert err_pos < 1e-3 and err_lat < 3e-3
+    parity("chain.encoded", rel_l2(lat.cpu(), lat_o), 1e-5)
+    parity("chain.sampled", err_lat, 3e-3)
+    parity("chain.decoded", err_pos, 1e-3)
 
 
 def test_graph_replay_matches_eager_bits(dev):

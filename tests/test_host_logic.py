@@ -54,7 +54,12 @@ def test_module_state_dict_contract_and_errors():
         sd = net.state_dict()
         assert set(sd) == set(ref)
         assert all(sd[k].shape == ref[k].shape for k in ref)
-        net.load_state_dict({"_orig_mod." + k if False else k: v for k, v in ref.items()})
+        net.load_state_dict(ref)
+        assert all(torch.equal(net.state_dict()[k], ref[k]) for k in ref)
+        # a backbone saved while wrapped by torch.compile carries the `_orig_mod.` prefix (second_stage/md17.py:53-55)
+        other = latent_net.random_params(sh, seed=1)
+        net.load_state_dict({"_orig_mod." + k: v for k, v in other.items()})
+        assert all(torch.equal(net.state_dict()[k], other[k]) for k in other)
     z = LatentSIV3(depth=1, in_dim=8, hidden_size=64, num_heads=4)  # reset_parameters=True: AdaLN-Zero init
     assert float(z.blocks[0].modulation.lin.weight.detach().abs().sum()) == 0 and float(z.linear.weight.detach().abs().sum()) == 0
     with pytest.raises(ValueError):
@@ -309,3 +314,23 @@ def test_decoder_query_splitter_rows_reordered(golden):
     ref = torch.nn.functional.linear(lat, w, b).reshape(3, 5, D, N).permute(0, 1, 3, 2).reshape(3, 5 * N, D)
     mine = torch.nn.functional.linear(lat, dec._sd["decoder.extender.rows"], dec._sd["decoder.extender.rows_bias"]).reshape(3, 5 * N, D)
     assert N == 4 and torch.equal(ref, mine)
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself and print ONE JSON line with n_gpus 2.  The sampling call
+    is stubbed (no GPU here) and the collective runs over gloo; the rank start-up, the barrier / max-over-ranks timing, the all_gather of
+    the final latents and the single-line contract are the real code."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                          "--stub-compute", "--batch", "3", "--no-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo" and out["steps"] == 2
+    assert out["config"]["global_batch"] == 6 and out["gather_ms"] is not None and out["value"] > 0 and out["scaling"] == "weak"
+    assert "stub" in out["data"]
+    # the product path refuses gloo / CPU
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--no-cpu"], env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0

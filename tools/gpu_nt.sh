@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 for p in 0 32; do
   out=$GRAFT_REPO_ROOT/gpurun_out/nt_$p
-  LSL_PROBE=$p rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $out.log 2>&1
+  LSL_PROBE=$p rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/bench_exp.py --steps 1 --warmup 0 --no-cpu > $out.log 2>&1
   python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $out | grep -A2 "EpiLinear1" | head -4
 done
 cd $GRAFT_REPO_ROOT

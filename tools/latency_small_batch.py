@@ -37,4 +37,4 @@ for name, (kw, T, L, ns) in CASES.items():
             out = drv.sample_latents(lat, y=y, init=init)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print(f"LSL_GRAPH={os.environ.get('LSL_GRAPH', '1')}  {name}  batch {B:4d}: {dt * 1e3:7.2f} ms per call  ({B / dt:9.1f} trajectories/s)  checksum {float(out.abs().mean()):.6f}")
+        print(f"LSL_GRAPH={os.environ.get('LSL_GRAPH', '0')}  {name}  batch {B:4d}: {dt * 1e3:7.2f} ms per call  ({B / dt:9.1f} trajectories/s)  checksum {float(out.abs().mean()):.6f}")

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../lam_slide_amd/csrc/k_gemm.cuh"
+#include "../lam_slide_amd/csrc/k_gemm.hip.h"
 
 template <int MI, int NJ, int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64) probe(float *out, int iters) {
