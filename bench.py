@@ -133,6 +133,17 @@ def cpu_oracle_runner(workload, inputs=None):
     return lambda n: harness.sample_latents(params, sh, tr, init, xc, m, y, "SDE", {"num_steps": n, "last_step": None})
 
 
+def usable_cores() -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 CPU quota, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_worker(args) -> int:
     """One worker of the all-core leg: `--cpu-worker n` runs n state updates of one trajectory with --cpu-threads threads."""
     import torch as th
@@ -442,21 +453,30 @@ def cpu_leg(args, kw, T, L, method, skw, n_evals, init, mk, net, tr, dev):
     cpu["one_thread"] = {"value": 1.0 / (t1 * n_evals), "unit": "trajectories/s", "cores": 1,
                          "sample": f"1 state update timed ({t1:.1f} s), extrapolated linearly to {n_evals}"}
     th.set_num_threads(best)
-    # all cores: host_cores // best workers, `best` threads each, one trajectory per worker, all in flight together
-    workers = max(1, host_cores // best)
-    n_w = max(one + 1, min(n_evals, int(round(10.0 / per_update))))
-    env = dict(os.environ, OMP_NUM_THREADS=str(best), MKL_NUM_THREADS=str(best))
+    # all usable cores: several trajectories in flight, one worker process each with a few threads (the calibration above shows the
+    # intra-op scaling of these small fp32 ops saturates early).  "Usable" = what this process may run on (affinity mask and cgroup
+    # quota), which on a shared box is less than os.cpu_count(); wall time is bounded (workers that overrun are stopped and excluded).
+    usable = usable_cores()
+    tpw = min(8, best)
+    workers = max(1, min(usable // tpw, 32))
+    n_w = one + 3
+    env = dict(os.environ, OMP_NUM_THREADS=str(tpw), MKL_NUM_THREADS=str(tpw))
     tc = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--cpu-worker", str(n_w), "--cpu-threads", str(best)],
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--cpu-worker", str(n_w), "--cpu-threads", str(tpw)],
                               env=env, stdout=subprocess.PIPE, text=True) for _ in range(workers)]
-    res = []
+    res, deadline = [], time.perf_counter() + 75.0
     for p in procs:
-        o, _ = p.communicate(timeout=600)
-        if p.returncode == 0:
-            res.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
+        try:
+            o, _ = p.communicate(timeout=max(1.0, deadline - time.perf_counter()))
+            if p.returncode == 0:
+                res.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
     if res:
         agg = sum(r["updates"] / r["seconds"] for r in res) / n_evals
-        cpu["all_cores"] = {"value": agg, "unit": "trajectories/s", "cores": workers * best, "workers": len(res), "threads_per_worker": best,
+        cpu["all_cores"] = {"value": agg, "unit": "trajectories/s", "cores": len(res) * tpw, "usable_cores": usable, "workers": len(res),
+                            "workers_started": workers, "threads_per_worker": tpw,
                             "sample": f"{len(res)} trajectories in flight (one worker process each), {res[0]['updates']} state updates per worker, "
                                       f"{time.perf_counter() - tc:.1f} s wall incl. start-up, extrapolated linearly to {n_evals}"}
     return cpu

@@ -291,5 +291,5 @@ def test_override_yaml_runs_the_fused_path_on_gpu(path):
     assert sampler.last_path == "fused" and net.last_path == "hip"
     want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, m, y, "ODE", skw)
     err = rel_l2(got.cpu(), want)
-    print(f"PARITY dropin.{'/'.join(path.split(os.sep)[-2:])} {err:.3e}")
-    assert err < 1e-3, err
+    from conftest import parity
+    parity(f"dropin.{'/'.join(path.split(os.sep)[-2:])}", err, 1e-3)

@@ -1,12 +1,15 @@
 """GPU parity tests: the HIP path (through the C ABI, via lam_slide_amd) against the CPU oracle and the
 committed golden vectors.
 
-Tolerances (relative L2 unless noted):
-  * fp32-only kernels (conditioning vector, modulation tables): 2e-5
-  * one block / one network evaluation with bf16 MFMA operands, fp32 accumulate: 1e-2 on a block's update,
-    5e-3 on the network output
-  * sampler end to end: final latents 3e-3; decoded coordinates 1e-3 (BASELINE.json north_star)
-  * integer / indexing behaviour (sharding, chunking, batch independence): bit-exact
+Tolerances (relative L2 unless noted).  Every bar is about 5x the value measured on MI355X in round 2 (gpurun log excerpt in
+profiles/r02_parity.txt; conftest.parity prints "PARITY name measured bar" so both are on record); the north-star bar of
+BASELINE.json (decoded coordinates within 1e-3) is 4-25x looser than any of them.
+  * fp32-only kernels (conditioning vector, modulation tables): measured 5-7e-7, bar 5e-6
+  * one block update with bf16 MFMA operands against the reference's own intermediates: measured 3-4e-3 of the UPDATE, bar 1e-2
+  * one network evaluation: measured 0.3-1.4e-4, bars 4-6e-4
+  * samplers end to end: final latents measured 0.4-2.4e-4, bars 6e-4..1e-3; decoded coordinates measured 2.6-5.9e-5, bars 1.5-3e-4
+  * fp32 stage-1 encode / decode: measured 2.4-3.8e-7, bar 2e-6
+  * integer / indexing behaviour (sharding, chunking, batch independence, K-folding, graph replay): bit-exact
 """
 import ctypes as C
 
@@ -104,7 +107,7 @@ def test_forward_f1(golden, dev):
     net = build_net(sh, f.group("p"), dev)
     out = net(f["x"].to(dev), f["t"].to(dev), f["x_cond"].to(dev), f["mask"].to(dev), f["y"].to(dev))
     assert net.last_path == "hip"
-    parity("f1.forward", rel_l2(out.cpu(), f.group("taps")["out"]), 5e-3)
+    parity("f1.forward", rel_l2(out.cpu(), f.group("taps")["out"]), 5e-4)
 
 
 def test_forward_shape_classes(golden, dev):
@@ -119,7 +122,7 @@ def test_forward_shape_classes(golden, dev):
         net = build_net(sh, p, dev)
         y = g.get("y")
         out = net(g["x"].to(dev), g["t"].to(dev), g["x_cond"].to(dev), g["mask"].to(dev), y.to(dev) if y is not None else None)
-        parity(f"f2.{n}", rel_l2(out.cpu(), g["out"]), 5e-3)
+        parity(f"f2.{n}", rel_l2(out.cpu(), g["out"]), 6e-4)
 
 
 def _sampler(net, path="GVP", pred="data", **kw):
@@ -136,11 +139,11 @@ def test_ode_samplers_against_reference_outputs(golden, dev):
         s = _sampler(net)
         res = s.get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": n})(init, net.forward, x_cond=xc, x_cond_mask=mask)
         assert s.last_path == "fused" and len(res) == n
-        parity(f"f4.ode{n}", rel_l2(res[-1].cpu(), f[f"ode{n}"]), 3e-3)
+        parity(f"f4.ode{n}", rel_l2(res[-1].cpu(), f[f"ode{n}"]), 6e-4)
     for path, pred in (("Linear", "velocity"), ("Linear", "data"), ("VP", "noise"), ("GVP", "score")):
         s = _sampler(net, path, pred)
         res = s.get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": 6})(init, net, x_cond=xc, x_cond_mask=mask)
-        parity(f"f4.ode6.{path}.{pred}", rel_l2(res[-1].cpu(), f[f"ode6.{path}.{pred}"]), 3e-3)
+        parity(f"f4.ode6.{path}.{pred}", rel_l2(res[-1].cpu(), f[f"ode6.{path}.{pred}"]), 6e-4)
 
 
 def test_sde_samplers_with_stored_noise(golden, dev):
@@ -154,15 +157,15 @@ def test_sde_samplers_with_stored_noise(golden, dev):
         fn = s.sample_sde(sampling_method="Euler", diffusion_form=form, last_step=last, num_steps=n, noise=f[tag + ".noise"].to(dev))
         res = fn(init, net.forward, x_cond=xc, x_cond_mask=mask)
         assert s.last_path == "fused" and len(res) == n
-        parity(f"f4.{tag}.final", rel_l2(res[-1].cpu(), f[tag + ".final"]), 3e-3)
-        parity(f"f4.{tag}.penultimate", rel_l2(res[-2].cpu(), f[tag + ".penultimate"]), 3e-3)
+        parity(f"f4.{tag}.final", rel_l2(res[-1].cpu(), f[tag + ".final"]), 7e-4)
+        parity(f"f4.{tag}.penultimate", rel_l2(res[-2].cpu(), f[tag + ".penultimate"]), 7e-4)
     # Heun goes through the generic loop (network still on the HIP path)
     tag = "sde5.linear.Mean.Heun"
     s = _sampler(net)
     fn = s.sample_sde(sampling_method="Heun", diffusion_form="linear", last_step="Mean", num_steps=5, noise=f[tag + ".noise"].to(dev))
     res = fn(init, net.forward, x_cond=xc, x_cond_mask=mask)
     assert s.last_path == "generic" and net.last_path == "hip" and len(res) == 5
-    parity(f"f4.{tag}.final", rel_l2(res[-1].cpu(), f[tag + ".final"]), 3e-3)
+    parity(f"f4.{tag}.final", rel_l2(res[-1].cpu(), f[tag + ".final"]), 1e-3)
 
 
 def test_cfg1_decoded_coordinates(golden, dev):
@@ -187,8 +190,8 @@ def test_cfg1_decoded_coordinates(golden, dev):
     pos_got = harness.decode(d.group("p"), harness.DecoderShape(), got[0], ent)
     pos_want = harness.decode(d.group("p"), harness.DecoderShape(), want[0], ent)
     pos_err = rel_l2(pos_got, pos_want)
-    parity("cfg1.latents", lat_err, 3e-3)
-    parity("cfg1.decoded_coords", pos_err, 1e-3)
+    parity("cfg1.latents", lat_err, 5e-4)
+    parity("cfg1.decoded_coords", pos_err, 3e-4)
 
 
 def test_batch_independence_and_chunking_bit_exact(dev):
@@ -303,7 +306,7 @@ def test_baseline_config_shapes(name, dev):
         got = s.get_sample_fn("ODE", skw)(init.to(dev), net.forward, **mk)[-1]
         want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, mask, y, "ODE", skw)
     assert s.last_path == "fused"
-    parity(f"config.{name}.latents", rel_l2(got.cpu(), want), 3e-3)
+    parity(f"config.{name}.latents", rel_l2(got.cpu(), want), {"pedestrian": 1e-3, "nba": 9e-4}.get(name, 6e-4))
 
 
 def test_k_sample_batching_equals_sequential_calls(dev):
@@ -331,7 +334,7 @@ def test_stage1_decode_against_reference_positions(golden, dev):
     d = golden("f6_decode.npz")
     dec = Stage1Decoder(d.group("p"), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16, act="gelu_erf")
     pos = dec.decode(d["z"].to(dev), d["entities"].to(dev)).cpu()
-    parity("f6.decode", rel_l2(pos, d["pos"]), 1e-5)
+    parity("f6.decode", rel_l2(pos, d["pos"]), 2e-6)
     # frames are independent: any subset decodes to the same bits
     part = dec.decode(d["z"][1:3].to(dev), d["entities"][1:3].to(dev)).cpu()
     assert torch.equal(part, pos[1:3])
@@ -357,7 +360,7 @@ def test_sample_then_decode_on_device(golden, dev):
     ent = torch.arange(21)[None].expand(30, 21)
     pos = dec.decode(final[0], ent.to(dev)).cpu()
     want = harness.decode(d.group("p"), harness.DecoderShape(), f["final"][0], ent)
-    parity("cfg1.sample_decode_on_device", rel_l2(pos, want), 1e-3)
+    parity("cfg1.sample_decode_on_device", rel_l2(pos, want), 3e-4)
 
 
 def test_stage1_encode_against_reference_latents(golden, dev):
@@ -367,7 +370,7 @@ def test_stage1_encode_against_reference_latents(golden, dev):
     d = golden("f7_encode.npz")
     enc = Stage1Encoder(d.group("p"), num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16, act="gelu_erf")
     z = enc.encode(d["x"].to(dev), d["entities"].to(dev), d["mask"].to(dev)).cpu()
-    parity("f7.encode", rel_l2(z, d["z"]), 1e-5)
+    parity("f7.encode", rel_l2(z, d["z"]), 2e-6)
     part = enc.encode(d["x"][1:2].to(dev), d["entities"][1:2].to(dev), d["mask"][1:2].to(dev)).cpu()
     assert torch.equal(part, z[1:2])
     # masked-out entities do not influence the latents
@@ -385,7 +388,7 @@ def test_stage1_decode_query_splitter_cross_block_tanh(golden, dev):
     dec = Stage1Decoder(d.group("p"), num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16, act="gelu_tanh")
     assert (dec.num_split, dec.num_block_cross) == (4, 1)
     pos = dec.decode(d["z"].to(dev), d["entities"].to(dev)).cpu()
-    parity("f8.decode_split", rel_l2(pos, d["pos"]), 1e-5)
+    parity("f8.decode_split", rel_l2(pos, d["pos"]), 2e-6)
 
 
 RANDOM_SHAPES = {
@@ -418,7 +421,7 @@ def test_forward_edge_shapes_vs_oracle(name, dev):
     want = latent_net.forward(p, sh, x, t, xc, mask, y)
     got = net(x.to(dev), t.to(dev), xc.to(dev), mask.to(dev), y.to(dev) if y is not None else None).cpu()
     assert net.last_path == "hip" and torch.isfinite(got).all()
-    parity(f"edge.{name}", rel_l2(got, want), 5e-3)
+    parity(f"edge.{name}", rel_l2(got, want), 4e-4)
 
 
 def test_full_chain_encode_sample_decode_on_device(golden, dev):
@@ -457,9 +460,9 @@ def test_full_chain_encode_sample_decode_on_device(golden, dev):
     final_o = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, m, None, "ODE", skw)
     pos_o = harness.decode(d.group("p"), harness.DecoderShape(), final_o.reshape(B * T, 48, 32), ent)
     err_lat, err_pos = rel_l2(final.cpu(), final_o), rel_l2(pos, pos_o)
-    parity("chain.encoded", rel_l2(lat.cpu(), lat_o), 1e-5)
-    parity("chain.sampled", err_lat, 3e-3)
-    parity("chain.decoded", err_pos, 1e-3)
+    parity("chain.encoded", rel_l2(lat.cpu(), lat_o), 2e-6)
+    parity("chain.sampled", err_lat, 4e-4)
+    parity("chain.decoded", err_pos, 1.5e-4)
 
 
 def test_graph_replay_matches_eager_bits(dev):
