@@ -53,6 +53,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 
+// v + (value of lane ^ 32) as one VALU exchange (gfx950 v_permlane32_swap) + one add, instead of ds_bpermute through the LDS queue.
+// v_permlane32_swap vdst, src swaps lanes 32-63 of vdst with lanes 0-31 of src; with both = v the results are (low half's value in
+// every lane, high half's value in every lane), summed in the same order on both halves: the two lanes of a token get identical bits.
+__device__ __forceinline__ float half_pair_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)p[0]) + __builtin_bit_cast(float, (unsigned)p[1]);
+}
+
 // value of lane ^ 1 / lane ^ 2 through DPP quad permutes (a VALU move; __shfl_xor goes through ds_bpermute and the LDS queue)
 __device__ __forceinline__ float quad_xor1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));

@@ -59,6 +59,7 @@ struct GemmCfg {
     static constexpr size_t lds_bytes =
         !PERSIST ? (ring_bytes > stage_bytes ? ring_bytes : stage_bytes) : stage_in_slot1 ? ring_bytes : ring_bytes + stage_bytes;
     static_assert(lds_bytes <= 163840, "LDS budget (160 KiB per workgroup)");
+    // + the bias vector (Epi::lds_bias): nft * BF floats behind lds_bytes, sized by the launcher
 };
 
 template <int BF, int BT, int NWF, int NWT, int BK, int NS, bool PERSIST, class Epi>
@@ -141,18 +142,44 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
         if (odd)
             for (int i = 0; i < -g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    // Epilogues with a per-feature bias (linear1) keep the whole bias vector in LDS behind the ring / staging for the lifetime of the
+    // workgroup (F1 floats: 10 KiB for D = 512) and start every tile's accumulators FROM it: the bias costs no VALU instruction and no
+    // global-load latency in the epilogue, and replaces the zero fill.
+    const float *bias_lds = reinterpret_cast<const float *>(smem + Cfg::lds_bytes);
+    if constexpr (Epi::lds_bias) {
+        const int fpad = nft * BF;  // (the bias buffer is padded to whole 256-feature tiles by the host)
+        for (int i = tid * 4; i < fpad; i += NW * 64 * 4)
+            *reinterpret_cast<float4 *>(smem + Cfg::lds_bytes + (size_t)i * 4) = *reinterpret_cast<const float4 *>(epi.bias + i);
+        __syncthreads();
+    }
     set_tile(blockIdx.x);
     prologue();
     bool prev_full = false;  // the tile whose epilogue ran last was a full one (all its stores were issued)
     for (int v = blockIdx.x; v < ntiles; v += PERSIST ? gridDim.x : ntiles) {
     const bool first_tile = v == (int)blockIdx.x;
     f32x16 acc[MI][NJ];
+    if constexpr (Epi::lds_bias) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 b = *reinterpret_cast<const float4 *>(bias_lds + f_base + wf * WF + i * 32 + 8 * q4 + 4 * hf);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j][4 * q4] = b.x;
+                    acc[i][j][4 * q4 + 1] = b.y;
+                    acc[i][j][4 * q4 + 2] = b.z;
+                    acc[i][j][4 * q4 + 3] = b.w;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
         // k-tiles after this one that are already in flight: min(nk - 1 - kt, NS - 2); wait for everything older.
@@ -224,19 +251,23 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
 // v: as is; mlp: erf-GELU.  Output bf16:  qkv[n][0 .. 3*HHD)  and  z[n][HHD .. HHD+M).
 // (mmdit.py:241-248, 129-148, 85-90, 11-18)
 //
-// Two phases per slab of 64 features x 32 tokens, through wave-private LDS (fp32, 8 KiB per wave):
-//   A  the raw accumulators are written column-wise (lane = token, 4 consecutive features per 16-byte chunk);
-//   B  they are read back row-wise: 8 lanes cover one token's 64 features, a lane owns 8 consecutive features
-//      (a quarter of a 32-wide head, half of a 16-wide one), so the RoPE pairs are lane-local, the head's sum of
-//      squares is 1-2 xor-shuffles, and the result leaves as one 16-byte store per lane = whole 128-byte row
-//      segments, 8 token rows per instruction.
-// Phase B needs ~40 VGPRs and none of the accumulators of the other slabs, which is what lets the kernel run at the
-// 128-VGPR budget of 4 waves per SIMD.
+// Round-2 form.  All arithmetic runs in the ACCUMULATOR layout: a lane holds one token (column lane & 31) and, per 32 x 32 tile, 16 of
+// the tile's 32 features in 4 groups of 4 consecutive ones (rows 8 g + 4 hf .. + 3), so
+//   * a tile lies inside one section (q | k | v | mlp: sections start on multiples of 32) -> the branch is wave-uniform,
+//   * RoPE pairs (2p, 2p+1) are lane-local; the QK-norm scales are folded into the rotation table once per call
+//     (k_rope_scaled: (c s0, sn s1, sn s0, c s1) per pair), which a lane loads once per token column and keeps across head tiles,
+//   * the head's sum of squares is 16 (8) FMAs plus ONE exchange with lane ^ 32 (v_permlane32_swap),
+//   * GELU is element-wise.
+// Only the finished bf16 values cross LDS (round 1 transposed the raw fp32 accumulators and did the arithmetic row-wise: twice the
+// LDS bytes and redundant per-row table loads): per slab of 64 features x 32 tokens a lane writes its 4 + 4 packed 8-byte groups
+// into a 4 KiB wave-private image [token][64 features] (16-byte chunks XOR-swizzled by the row) and the wave reads it back row-wise,
+// 16 bytes per lane = whole 128-byte row segments, 8 token rows per store instruction.
 template <int HDP>
 struct EpiLinear1 {
-    const float *bias;     // [F1]
-    const float *qs, *ks;  // [HDP]
-    const float2 *rope;    // [n_pos][HDP/2] (cos, sin)
+    const float *bias;     // [F1 rounded up to 256]
+    const float *qs, *ks;  // [HDP]                                   (piece form below: experiments only)
+    const float2 *rope;    // [n_pos][HDP/2] (cos, sin)               (piece form below: experiments only)
+    const float4 *rope_q, *rope_k;  // [n_pos][HDP/2] (c s0, sn s1, sn s0, c s1) with the query / key norm scales folded in
     u16 *qkv;              // [N][3*HHD]
     u16 *z;                // [N][HHD + M]
     int HHD, M;
@@ -244,85 +275,117 @@ struct EpiLinear1 {
     unsigned div_magic, mod_magic;  // floor(2^32 / d) + 1 for d = pos_div, pos_mod (0 when d == 1): n / d == umulhi(n, magic) for n * d < 2^32
     float inv_hd;          // 1 / true head_dim
     float q_premul;        // head_dim^-0.5 * log2(e), folded into q for the exp2-based softmax
-    int probe;             // TIMING PROBES ONLY (results wrong): bit3 skip norm/RoPE/GELU math, bit4 skip the global stores;
-                           // bit5 (set by the launcher, results unchanged): streaming stores
+    int probe;             // bit5 (set by the launcher): streaming stores.  bits 3 / 4 (skip math / skip stores) are timing probes that
+                           // exist only in -DLSL_EXPERIMENTS builds
 
+    static constexpr bool lds_bias = true;  // the kernel starts the accumulators from the bias (kept in LDS); run() must not add it again
     template <int WF, int WT>
-    static constexpr size_t wave_stage_bytes() { return (size_t)64 * 32 * 4; }
+    static constexpr size_t wave_stage_bytes() { return (size_t)32 * 64 * 2; }
     // global stores a wave issues for a FULL tile (a lower bound of its vector-memory instructions in the epilogue): what a counted
     // s_waitcnt may leave in flight when a persistent workgroup only needs the LDS-DMA loads it issued BEFORE the epilogue
     template <int MI, int NJ>
     static constexpr int min_store_ops() { return MI * NJ * 2; }
 
+    static __device__ __forceinline__ int soff(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
     template <int MI, int NJ>
     __device__ __forceinline__ void run(f32x16 (&acc)[MI][NJ], char *stage, int f_wave, int n_wave, int lane, int F, int N) const {
         static_assert(MI % 2 == 0, "feature slabs are 64 wide");
-        constexpr int CH = 16;  // 64 fp32 features = 16 chunks of 16 B per staged token row
+        constexpr int NCO = HDP == 32 ? 8 : 4;  // rotation pairs a lane owns per head
+        // opaque copy of the lane id: without it hipcc hoists every per-lane 64-bit address of this epilogue out of the persistent tile
+        // loop and keeps them alive across the main loop - as scratch spills (15 pointer pairs)
+        asm volatile("" : "+v"(lane));
         const int r = lane & 31, hf = lane >> 5;
-        const int tr = lane >> 3, c = lane & 7;  // phase B: token row within a group of 8, 8-feature chunk
+        const int tr = lane >> 3, c = lane & 7;  // read-back: token row within a group of 8, 8-feature chunk
 #pragma unroll
         for (int i0 = 0; i0 < MI; i0 += 2) {
             const int fs = f_wave + i0 * 32;  // first feature of the slab
             if (fs >= F) continue;            // wave-uniform
-            const int f = fs + 8 * c;         // this lane's 8 features in phase B
-            const bool f_ok = f < F;
-            const int sec_out = f / HHD;      // 0 q, 1 k, 2 v, >= 3 mlp
-            const int sec = LSL_PROBE(probe, 8) ? 2 : sec_out;
-            const int d = f & (HDP - 1);      // channel of the first feature inside its head (sections start on heads)
-            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, s0 = b0, s1 = b0;
-            if (f_ok) {
-                b0 = *reinterpret_cast<const float4 *>(bias + f);
-                b1 = *reinterpret_cast<const float4 *>(bias + f + 4);
-                if (sec < 2) {
-                    const float *sc = sec == 0 ? qs : ks;
-                    s0 = *reinterpret_cast<const float4 *>(sc + d);
-                    s1 = *reinterpret_cast<const float4 *>(sc + d + 4);
-                }
-            }
-            const float post = sec == 0 ? q_premul : 1.0f;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                // phase A
+                const unsigned nn = (unsigned)min(n_wave + j * 32 + r, N - 1);
+                const unsigned n1 = div_magic ? __umulhi(nn, div_magic) : nn;
+                const unsigned pos = mod_magic ? n1 - __umulhi(n1, mod_magic) * (unsigned)pos_mod : 0u;
+                int csec = -1;
+                float4 co[NCO];
 #pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int ft = fs + ii * 32;
+                    if (ft >= F) continue;  // wave-uniform (F is a multiple of 32)
+                    const int sec_t = (ft >= HHD) + (ft >= 2 * HHD) + (ft >= 3 * HHD);  // 0 q, 1 k, 2 v, 3 mlp: wave-uniform
+                    const int sec = LSL_PROBE(probe, 8) ? 2 : sec_t;
+                    __builtin_amdgcn_sched_barrier(0);  // one tile's temporaries live at a time (256-VGPR budget beside 128 accumulators)
+                    const f32x16 &a = acc[i0 + ii][j];  // (bias included: the kernel started the accumulators from it)
+                    float x[16];
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x16 &a = acc[i0 + ii][j];
-                        *reinterpret_cast<float4 *>(stage + stage_off<CH>(r, 8 * ii + 2 * q4 + hf)) =
-                            make_float4(a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]);
+                    for (int e = 0; e < 16; ++e) x[e] = a[e];
+                    if (sec < 2) {
+                        if (sec != csec) {  // (a wave tile usually lies in one section: loaded once per token column)
+                            const float4 *tab = (sec == 0 ? rope_q : rope_k) + (size_t)pos * (HDP / 2) + 2 * hf;
+#pragma unroll
+                            for (int k = 0; k < NCO; ++k) co[k] = tab[4 * (k >> 1) + (k & 1)];
+                            csec = sec;
+                        }
+                        const float post = sec == 0 ? q_premul : 1.0f;
+                        if (HDP == 32) {
+                            float ss = 0.0f;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) ss = fmaf(x[e], x[e], ss);
+                            ss = half_pair_sum(ss);
+                            const float rr = rsqrtf(fmaf(ss, inv_hd, 1e-6f)) * post;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float x0 = x[2 * k], x1 = x[2 * k + 1];
+                                x[2 * k] = rr * fmaf(co[k].x, x0, -co[k].y * x1);
+                                x[2 * k + 1] = rr * fmaf(co[k].z, x0, co[k].w * x1);
+                            }
+                        } else {  // two 16-wide heads per tile: rows 0-15 and 16-31
+                            float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                sa = fmaf(x[e], x[e], sa);
+                                sb = fmaf(x[8 + e], x[8 + e], sb);
+                            }
+                            sa = half_pair_sum(sa);
+                            sb = half_pair_sum(sb);
+                            const float ra = rsqrtf(fmaf(sa, inv_hd, 1e-6f)) * post, rb = rsqrtf(fmaf(sb, inv_hd, 1e-6f)) * post;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float x0 = x[2 * k], x1 = x[2 * k + 1], rr = k < 4 ? ra : rb;
+                                const float4 cf = co[k & 3];
+                                x[2 * k] = rr * fmaf(cf.x, x0, -cf.y * x1);
+                                x[2 * k + 1] = rr * fmaf(cf.z, x0, cf.w * x1);
+                            }
+                        }
+                    } else if (sec >= 3) {  // groups of 4: bounds the temporaries of the independent GELU chains (16 at once spill)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[4 * g + e] = gelu_fast(x[4 * g + e]);
+                            const u32x2 pk = {pack2(x[4 * g], x[4 * g + 1]), pack2(x[4 * g + 2], x[4 * g + 3])};
+                            *reinterpret_cast<u32x2 *>(stage + soff(r, 4 * ii + g) + 8 * hf) = pk;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
-                // phase B
-#pragma unroll 2
+                    if (sec < 3) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const u32x2 pk = {pack2(x[4 * g], x[4 * g + 1]), pack2(x[4 * g + 2], x[4 * g + 3])};
+                            *reinterpret_cast<u32x2 *>(stage + soff(r, 4 * ii + g) + 8 * hf) = pk;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // read back row-wise: 8 lanes cover the 128-byte slab of one token row; 8 token rows per instruction
+                const int f = fs + 8 * c;
+                const bool f_ok = f < F;
+                const bool to_qkv = f < 3 * HHD;
+#pragma unroll
                 for (int row0 = 0; row0 < 32; row0 += 8) {
                     const int row = row0 + tr, n = n_wave + j * 32 + row;
-                    const float4 lo = *reinterpret_cast<const float4 *>(stage + stage_off<CH>(row, 2 * c));
-                    const float4 hi = *reinterpret_cast<const float4 *>(stage + stage_off<CH>(row, 2 * c + 1));
-                    float v[8] = {lo.x + b0.x, lo.y + b0.y, lo.z + b0.z, lo.w + b0.w, hi.x + b1.x, hi.y + b1.y, hi.z + b1.z, hi.w + b1.w};
-                    if (sec < 2) {
-                        float ss = 0.0f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
-                        ss += quad_xor1(ss);
-                        if (HDP == 32) ss += quad_xor2(ss);
-                        const float rr = rsqrtf(fmaf(ss, inv_hd, 1e-6f)) * post;
-                        const unsigned nn = (unsigned)min(n, N - 1);
-                        const unsigned n1 = div_magic ? __umulhi(nn, div_magic) : nn;
-                        const unsigned pos = mod_magic ? n1 - __umulhi(n1, mod_magic) * (unsigned)pos_mod : 0u;
-                        const float2 *tab = rope + (size_t)pos * (HDP / 2) + (d >> 1);
-                        const float4 c0 = *reinterpret_cast<const float4 *>(tab), c1 = *reinterpret_cast<const float4 *>(tab + 2);
-                        const float x0 = v[0] * rr * s0.x, x1 = v[1] * rr * s0.y, x2 = v[2] * rr * s0.z, x3 = v[3] * rr * s0.w;
-                        const float x4 = v[4] * rr * s1.x, x5 = v[5] * rr * s1.y, x6 = v[6] * rr * s1.z, x7 = v[7] * rr * s1.w;
-                        v[0] = c0.x * x0 - c0.y * x1; v[1] = c0.y * x0 + c0.x * x1;
-                        v[2] = c0.z * x2 - c0.w * x3; v[3] = c0.w * x2 + c0.z * x3;
-                        v[4] = c1.x * x4 - c1.y * x5; v[5] = c1.y * x4 + c1.x * x5;
-                        v[6] = c1.z * x6 - c1.w * x7; v[7] = c1.w * x6 + c1.z * x7;
-                    } else if (sec >= 3) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
-                    }
+                    const u32x4 pk = *reinterpret_cast<const u32x4 *>(stage + soff(row, c));
                     if (f_ok && n < N && !LSL_PROBE(probe, 16)) {
-                        const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                        u16 *dst = sec_out < 3 ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
+                        u16 *dst = to_qkv ? qkv + (size_t)n * (3 * HHD) + f : z + (size_t)n * (HHD + M) + (f - 2 * HHD);
                         store16(dst, pk, probe & 32);
                     }
                 }
@@ -433,6 +496,7 @@ struct EpiLinear2 {
     int probe;  // bit5: streaming stores (set by the launcher)
     unsigned tpt_magic;  // floor(2^32 / tokens_per_traj) + 1 (0 when tokens_per_traj == 1): n / tokens_per_traj by multiply-high
 
+    static constexpr bool lds_bias = false;
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return (size_t)32 * WT * 4; }  // one 32-feature slab of the wave tile
     template <int MI, int NJ>
@@ -542,6 +606,7 @@ template <class E>
 struct EpiPieces : E {
     __host__ __device__ EpiPieces(const E &e) : E(e) {}
 
+    static constexpr bool lds_bias = false;  // the piece forms add the bias themselves
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return E::pp_stage_bytes; }
     template <int MI, int NJ>

@@ -21,6 +21,33 @@ __global__ void k_rope_table(float2 *tab, int n_pos, int hd, int hdp, float thet
     tab[i] = v;
 }
 
+// RoPE table with the QK-norm scales of one attention block folded in (linear1 epilogue, k_gemm.hip.h):
+//   out[p][j] = (c s0, sn s1, sn s0, c s1),  (c, sn) = (cos, sin)(p * theta^(-2j/hd)),  s0 = scale[2j], s1 = scale[2j+1]
+// so that the rotated, scaled pair is  (o0, o1) = rr * (c s0 x0 - sn s1 x1,  sn s0 x0 + c s1 x1)  for the RMS factor rr
+// (mmdit.py:129-148 then 85-90).  One launch covers up to 16 (block, q|k) tables.
+struct RopeScaledJobs {
+    float4 *out[16];
+    const float *scale[16];
+    int n_pos[16];
+    int n_jobs;
+};
+__global__ void k_rope_scaled(RopeScaledJobs jobs, int hd, int hdp, float theta) {
+    const int job = blockIdx.y;
+    if (job >= jobs.n_jobs) return;
+    const int half = hdp / 2, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= jobs.n_pos[job] * half) return;
+    const int p = i / half, j = i % half;
+    float c = 1.0f, sn = 0.0f;
+    if (2 * j < hd) {
+        const double omega = 1.0 / pow((double)theta, (double)(2 * j) / (double)hd);
+        const double ang = (double)p * omega;
+        c = (float)cos(ang);
+        sn = (float)sin(ang);
+    }
+    const float s0 = jobs.scale[job][2 * j], s1 = jobs.scale[job][2 * j + 1];
+    jobs.out[job][i] = make_float4(c * s0, sn * s1, sn * s0, c * s1);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Sinusoidal time features (mmdit.py:93-115): args = (1000 t) * freqs in fp32, [cos | sin].
 // t_ptr == nullptr: every row uses t_scalar.

@@ -95,6 +95,8 @@ namespace {
 
 struct Workspace {
     float2 *rope_l, *rope_t;
+    float4 *rope_qk;        // [2 * depth blocks][q, k][max(T, L) positions][head_dim_pad / 2]: RoPE x QK-norm scales (k_rope_scaled)
+    size_t rope_qk_stride;  // float4 elements between consecutive (block, q|k) tables
     float *cond_emb, *h, *yemb, *tfeat, *hid, *vec, *mods;
     u16 *a, *qkv, *z;
     size_t bytes;
@@ -113,6 +115,8 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     Workspace ws;
     ws.rope_l = (float2 *)take((size_t)L * (d.head_dim_pad / 2) * sizeof(float2));
     ws.rope_t = (float2 *)take((size_t)T * (d.head_dim_pad / 2) * sizeof(float2));
+    ws.rope_qk_stride = (size_t)std::max(T, L) * (d.head_dim_pad / 2);
+    ws.rope_qk = (float4 *)take((size_t)4 * d.depth * ws.rope_qk_stride * sizeof(float4));
     ws.cond_emb = (float *)take(n * D * 4);
     ws.h = (float *)take(n * D * 4);
     ws.yemb = (float *)take((size_t)bc * D * 4);
@@ -291,8 +295,9 @@ int device_cus() {  // of the current device (entry points switch to the stream'
 template <int BF, int BT, int NWF, int NWT, int BK, int NS, bool PERSIST, class Epi>
 void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     auto kern = k_gemm_glds<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>;
-    constexpr size_t lds = GemmCfg<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>::lds_bytes;
-    LSL_ALLOW_LDS(kern, lds);
+    // + the bias vector of the whole GEMM, kept in LDS by epilogues that start the accumulators from it (k_gemm.hip.h)
+    const size_t lds = GemmCfg<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>::lds_bytes + (Epi::lds_bias ? (size_t)((g.F + BF - 1) / BF) * BF * 4 : 0);
+    LSL_ALLOW_LDS(kern, (size_t)163840);
     const int tiles = ((g.N + BT - 1) / BT) * ((g.F + BF - 1) / BF);
     int grid = tiles;
     if (PERSIST) {  // as many workgroups as fit at once (LDS-limited), a multiple of 8 so the XCD mapping stays regular
@@ -369,7 +374,7 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
     const int ragged_variant = std::is_same<Epi, EpiLinear2>::value && K % 64 == 0 ? 11 : 10;  // measured on the D = 384 / 128 models
-    const int variant = forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 && K >= 512 ? 12 : K % 64 == 0 ? 5 : 6));
+    const int variant = forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 ? 12 : K % 64 == 0 ? 5 : 6));
     static const int probe = tune_int("LSL_PROBE", 0);
     static const int stagger = tune_int("LSL_STAGGER", 0);
     GemmArgs g{W, X, F, N, K, stagger, probe};
@@ -493,6 +498,21 @@ void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream
     const int half = m->d.head_dim_pad / 2;
     hipLaunchKernelGGL(k_rope_table, dim3((L * half + 255) / 256), dim3(256), 0, st, ws.rope_l, L, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
     hipLaunchKernelGGL(k_rope_table, dim3((T * half + 255) / 256), dim3(256), 0, st, ws.rope_t, T, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
+    // the same tables with each attention block's query / key norm scales folded in (spatial blocks: L positions, temporal: T)
+    const int nb = 2 * m->d.depth;
+    for (int b0 = 0; b0 < 2 * nb; b0 += 16) {
+        RopeScaledJobs jobs;
+        jobs.n_jobs = std::min(16, 2 * nb - b0);
+        int max_pos = 0;
+        for (int k = 0; k < jobs.n_jobs; ++k) {
+            const int t = b0 + k, bi = t >> 1;
+            jobs.out[k] = ws.rope_qk + (size_t)t * ws.rope_qk_stride;
+            jobs.scale[k] = (t & 1) ? m->blocks[bi].ks : m->blocks[bi].qs;
+            jobs.n_pos[k] = (bi & 1) ? T : L;
+            max_pos = std::max(max_pos, jobs.n_pos[k]);
+        }
+        hipLaunchKernelGGL(k_rope_scaled, dim3((max_pos * half + 255) / 256, jobs.n_jobs), dim3(256), 0, st, jobs, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
+    }
 }
 
 // one ParallelMLPAttentionV2 sub-block on h (in place): LN+modulate -> linear1 -> attention -> linear2
@@ -514,11 +534,13 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     auto magic_of = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };
     if ((unsigned long long)n * (unsigned)std::max(pdiv, pmod) >= (1ull << 32)) return fail(-3, "pass too large for the position arithmetic");
     if (d.head_dim_pad == 32) {
-        EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
+        EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
+                         ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->HHD, d.mlp_dim,
                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 0};
         launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st, m->HHD);
     } else {
-        EpiLinear1<16> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.qkv, ws.z, m->HHD, d.mlp_dim,
+        EpiLinear1<16> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
+                         ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->HHD, d.mlp_dim,
                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 0};
         launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st, m->HHD);
     }
@@ -626,6 +648,7 @@ int lsl_model_create(const lsl_model_desc *desc, lsl_model **out) try {
     if ((d.heads * d.head_dim_pad) % 32 != 0) return fail(-21, "heads * head_dim_pad must be a multiple of 32");
     if (d.mlp_dim <= 0 || d.mlp_dim % 32 != 0) return fail(-21, "mlp_dim %d must be a positive multiple of 32", d.mlp_dim);
     if ((d.heads * d.head_dim_pad + d.mlp_dim) % 64 != 0) return fail(-21, "heads*head_dim_pad + mlp_dim must be a multiple of 64");
+    if (3 * d.heads * d.head_dim_pad + d.mlp_dim > 7936) return fail(-21, "3 * heads * head_dim_pad + mlp_dim = %d too wide (the linear1 bias lives in LDS beside a 128 KiB operand ring: <= 7936)", 3 * d.heads * d.head_dim_pad + d.mlp_dim);
     if (d.in_dim <= 0 || d.in_dim > 128) return fail(-21, "in_dim %d unsupported (1..128)", d.in_dim);
     if (d.depth <= 0 || d.depth > 64) return fail(-21, "depth %d unsupported", d.depth);
     if (d.vec_in_dim < 0 || d.vec_in_dim > 512) return fail(-21, "vec_in_dim %d unsupported (<= 512)", d.vec_in_dim);
