@@ -105,6 +105,21 @@ __device__ __forceinline__ void store8(void *p, u32x2 v, bool nt) {
     else *reinterpret_cast<u32x2 *>(p) = v;
 }
 
+// 16-byte loads that are served by L2, past this CU's vector L1 (sc1 loads bypass L1 only: MI355X_MICROARCH.md, visibility table): for
+// rows this workgroup has just rewritten while L1 may still hold their old lines.  Buffer form (aux 16 = sc1) because hipcc counts it
+// in its s_waitcnt bookkeeping (an inline-asm load would not be) and drops the hint of __builtin_nontemporal_load on 16-byte vectors.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+struct L2Reader {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ explicit L2Reader(const void *base) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xFFFFFFFFu, 0x00020000);
+    }
+    __device__ __forceinline__ float4 load16(unsigned byte_offset) const {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_offset, 0, 16);
+        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    }
+};
+
 // Workgroup id remap so that consecutive logical tiles share an XCD's L2.  Hardware deals
 // workgroups round-robin over the 8 XCDs; this only affects speed, never results.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -24,6 +24,8 @@ struct GemmArgs {
     const u16 *W;  // [F][K] bf16
     const u16 *X;  // [N][K] bf16
     int F, N, K;
+    int rows;     // persistent kernels whose epilogue is a row owner (linear2): 1 = walk token tiles and run all their feature tiles back to
+                  // back (needed by the fused LayerNorm); 0 = flat tile list (small launches: more workgroups than token tiles)
     int stagger;  // persistent grids: initial delay of the second half of the workgroups, in units of 8128 cycles
     int probe;  // timing probes, honoured only in -DLSL_EXPERIMENTS builds (tools/), where they make results wrong: bit0 skip operand
                 // loads, bit1 skip LDS reads + MFMAs, bit2 skip epilogue.  The product library ignores the field.
@@ -95,10 +97,23 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
     const int lchunk = (swz_bk<BK>(lrow, lane % CPR) - lrow * ROWB) >> 4;  // logical chunk stored at this lane's slot
     const size_t piece_step = (size_t)NW * RPP * g.K;                       // elements between a wave's pieces
     const u16 *srcW = nullptr, *srcX = nullptr;
+    // Row-owner walk (persistent epilogues that finish whole token rows, Epi::row_owner): a workgroup takes token tiles
+    // blockIdx.x, blockIdx.x + gridDim.x, ... and runs ALL feature tiles of a token tile back to back, so that after the last one it
+    // holds complete rows of the output (linear2: the updated residual rows, ready for the next sub-block's LayerNorm).
+    const bool ROWS = PERSIST && Epi::row_owner && g.rows;
+    const int n_walk = ROWS ? ((ntt > (int)blockIdx.x) ? (ntt - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0) * nft : ntiles;
     auto set_tile = [&](int v) {
-        const int tile = xcd_remap(v, ntiles);
-        f_base = (tile % nft) * BF;
-        n_base = (tile / nft) * BT;
+        int tile_f, tile_n;
+        if (ROWS) {
+            tile_n = blockIdx.x + (v / nft) * gridDim.x;
+            tile_f = v % nft;
+        } else {
+            const int tile = xcd_remap(v, ntiles);
+            tile_f = tile % nft;
+            tile_n = tile / nft;
+        }
+        f_base = tile_f * BF;
+        n_base = tile_n * BT;
         srcW = g.W + (size_t)(f_base + lrow) * g.K + lchunk * 8;
         srcX = g.X + (size_t)(n_base + lrow) * g.K + lchunk * 8;
     };
@@ -152,11 +167,13 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
             *reinterpret_cast<float4 *>(smem + Cfg::lds_bytes + (size_t)i * 4) = *reinterpret_cast<const float4 *>(epi.bias + i);
         __syncthreads();
     }
-    set_tile(blockIdx.x);
+    const int v0 = ROWS ? 0 : (int)blockIdx.x, v_step = ROWS ? 1 : PERSIST ? (int)gridDim.x : ntiles;
+    if (v0 >= n_walk) return;
+    set_tile(v0);
     prologue();
     bool prev_full = false;  // the tile whose epilogue ran last was a full one (all its stores were issued)
-    for (int v = blockIdx.x; v < ntiles; v += PERSIST ? gridDim.x : ntiles) {
-    const bool first_tile = v == (int)blockIdx.x;
+    for (int v = v0; v < n_walk; v += v_step) {
+    const bool first_tile = v == v0;
     f32x16 acc[MI][NJ];
     if constexpr (Epi::lds_bias) {
 #pragma unroll
@@ -238,11 +255,16 @@ __global__ void __launch_bounds__(NWF *NWT * 64, (NWF * NWT / 4 > 2 ? NWF * NWT 
     __syncthreads();  // every wave is done with the operand ring
     const int fw = f_base + wf * WF, nw = n_base + wt * WT;
     prev_full = f_base + BF <= g.F && n_base + BT <= g.N && !LSL_PROBE(g.probe, 4);
-    if (PERSIST && v + (int)gridDim.x < ntiles) {  // stream the next tile's first k-tiles while this tile's epilogue runs
-        set_tile(v + gridDim.x);
+    const int n_tile = n_base;
+    const bool rows_done = ROWS && (v % nft) == nft - 1;  // this was the last feature tile of the token tile
+    if (PERSIST && v + v_step < n_walk) {  // stream the next tile's first k-tiles while this tile's epilogue runs
+        set_tile(v + v_step);
         prologue();
     }
     if (!LSL_PROBE(g.probe, 4)) epi.template run<MI, NJ>(acc, stage, fw, nw, lane, g.F, g.N);
+    if constexpr (PERSIST && Epi::row_owner) {
+        if (rows_done && !LSL_PROBE(g.probe, 4)) epi.finish_rows(n_tile, BT, tid, NW, g.N);
+    }
     }
 }
 
@@ -279,6 +301,7 @@ struct EpiLinear1 {
                            // exist only in -DLSL_EXPERIMENTS builds
 
     static constexpr bool lds_bias = true;  // the kernel starts the accumulators from the bias (kept in LDS); run() must not add it again
+    static constexpr bool row_owner = false;
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return (size_t)32 * 64 * 2; }
     // global stores a wave issues for a FULL tile (a lower bound of its vector-memory instructions in the epilogue): what a counted
@@ -495,8 +518,77 @@ struct EpiLinear2 {
     int D, mod_stride, tokens_per_traj;
     int probe;  // bit5: streaming stores (set by the launcher)
     unsigned tpt_magic;  // floor(2^32 / tokens_per_traj) + 1 (0 when tokens_per_traj == 1): n / tokens_per_traj by multiply-high
+    // Fused LayerNorm + modulate of the NEXT sub-block (persistent row-owner kernels, D a multiple of 256): once a workgroup has run
+    // every feature tile of a token tile it owns the updated rows h[n][0..D) and writes a = bf16(LN_{1e-6}(h) (1 + scale) + shift), the
+    // A operand of the next linear1, straight away (rows re-read from the XCD's L2).  MEASURED AND REJECTED (round 2, cfg 2): bit-identical
+    // to the standalone kernel, but the standalone LayerNorm (55 ms per step, HBM-bound with every CU streaming) only moves into the
+    // workgroup's own timeline, behind a full drain of its residual stores and at one workgroup's memory-level parallelism: linear2
+    // 197 -> 286 ms for 55 -> 7.5 ms of LayerNorm.  Compiled only with -DLSL_EXPERIMENTS (LSL_LN_FUSE=1); the product never takes it.
+    u16 *ln_out;                        // [N][D] bf16, or NULL
+    const float *ln_shift, *ln_scale;   // next sub-block's modulation rows (row stride mod_stride)
 
     static constexpr bool lds_bias = false;
+#ifdef LSL_EXPERIMENTS
+    static constexpr bool row_owner = true;
+#else
+    static constexpr bool row_owner = false;
+#endif
+
+    // same arithmetic, in the same order, as k_ln_modulate_v4 (k_small.hip.h): the fused and the standalone form give identical bits
+    __device__ __forceinline__ void finish_rows(int n_tile, int bt, int tid, int nwaves, int N) const {
+#ifdef LSL_EXPERIMENTS
+        if (!ln_out) return;  // uniform
+        // every wave's residual stores have to be in L2 before any wave re-reads the rows: drain, then the workgroup barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int Q = D >> 8;  // 256-feature quarters per row: 1 (D = 256) or 2 (D = 512)
+        const float invD = 1.0f / (float)D;
+        constexpr int G = 8;   // rows in flight per wave (the accumulators are dead here: registers are plentiful, latency is not)
+        const L2Reader hl2(h);  // (a pass holds at most 2^18 tokens x 2 KiB: offsets fit 32 bits)
+        for (int r0 = wave * G; r0 < bt; r0 += nwaves * G) {
+            float4 v[G][2];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int n = min(n_tile + r0 + u, N - 1);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)  // L1 still holds the rows as they were BEFORE the update: read past it (nt loads are L2-served)
+                    v[u][k] = k < Q ? hl2.load16((unsigned)(((size_t)n * D + 4 * lane + 256 * k) * 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int n = n_tile + r0 + u;
+                if (n >= N) break;  // uniform
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (k < Q) s += (v[u][k].x + v[u][k].y) + (v[u][k].z + v[u][k].w);
+                const float mean = wave_sum(s) * invD;
+                float q = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (k < Q) {
+                        const float dx = v[u][k].x - mean, dy = v[u][k].y - mean, dz = v[u][k].z - mean, dw = v[u][k].w - mean;
+                        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                    }
+                const float rstd = rsqrtf(wave_sum(q) * invD + 1e-6f);
+                const unsigned traj = tpt_magic ? __umulhi((unsigned)n, tpt_magic) : (unsigned)n;
+                const size_t mo = (size_t)traj * mod_stride;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (k < Q) {
+                        const int d = 4 * lane + 256 * k;
+                        const float4 sc = *reinterpret_cast<const float4 *>(ln_scale + mo + d);
+                        const float4 sf = *reinterpret_cast<const float4 *>(ln_shift + mo + d);
+                        const u32x2 pk = {pack2((v[u][k].x - mean) * rstd * (1.0f + sc.x) + sf.x, (v[u][k].y - mean) * rstd * (1.0f + sc.y) + sf.y),
+                                          pack2((v[u][k].z - mean) * rstd * (1.0f + sc.z) + sf.z, (v[u][k].w - mean) * rstd * (1.0f + sc.w) + sf.w)};
+                        store8(ln_out + (size_t)n * D + d, pk, probe & 32);
+                    }
+            }
+        }
+#endif
+    }
+
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return (size_t)32 * WT * 4; }  // one 32-feature slab of the wave tile
     template <int MI, int NJ>
@@ -607,6 +699,7 @@ struct EpiPieces : E {
     __host__ __device__ EpiPieces(const E &e) : E(e) {}
 
     static constexpr bool lds_bias = false;  // the piece forms add the bias themselves
+    static constexpr bool row_owner = E::row_owner;
     template <int WF, int WT>
     static constexpr size_t wave_stage_bytes() { return E::pp_stage_bytes; }
     template <int MI, int NJ>

@@ -298,15 +298,31 @@ void launch_gemm_glds(const GemmArgs &g, const Epi &epi, hipStream_t st) {
     // + the bias vector of the whole GEMM, kept in LDS by epilogues that start the accumulators from it (k_gemm.hip.h)
     const size_t lds = GemmCfg<BF, BT, NWF, NWT, BK, NS, PERSIST, Epi>::lds_bytes + (Epi::lds_bias ? (size_t)((g.F + BF - 1) / BF) * BF * 4 : 0);
     LSL_ALLOW_LDS(kern, (size_t)163840);
-    const int tiles = ((g.N + BT - 1) / BT) * ((g.F + BF - 1) / BF);
+    const int ntt = (g.N + BT - 1) / BT, tiles = ntt * ((g.F + BF - 1) / BF);
     int grid = tiles;
+    GemmArgs ga = g;
+    ga.rows = 0;
     if (PERSIST) {  // as many workgroups as fit at once (LDS-limited), a multiple of 8 so the XCD mapping stays regular
         const int per_cu = (int)(163840 / lds) < 1 ? 1 : (int)(163840 / lds);
         grid = device_cus() * per_cu;
         grid -= grid % 8;
         if (grid > tiles) grid = tiles;
+        // row-owner walk (the epilogue finishes whole token rows: fused LayerNorm of linear2) only when there are at least as many
+        // token tiles as workgroups; smaller launches keep the flat list, which spreads the feature tiles over more CUs
+        if (Epi::row_owner && g.rows && ntt >= grid) ga.rows = 1;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWF * NWT * 64), lds, st, g, epi);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWF * NWT * 64), lds, st, ga, epi);
+}
+// whether launch_gemm_glds would take the row-owner walk for this launch (the caller then lets the epilogue write the next LayerNorm)
+template <int BF, int BT, int NWF, int NWT, int BK, int NS, class Epi>
+bool gemm_rows_walk(int F, int N) {
+    const size_t lds = GemmCfg<BF, BT, NWF, NWT, BK, NS, true, Epi>::lds_bytes;
+    const int per_cu = (int)(163840 / lds) < 1 ? 1 : (int)(163840 / lds);
+    int grid = device_cus() * per_cu;
+    grid -= grid % 8;
+    const int ntt = (N + BT - 1) / BT, tiles = ntt * ((F + BF - 1) / BF);
+    if (grid > tiles) grid = tiles;
+    return ntt >= grid;
 }
 
 #ifdef LSL_EXPERIMENTS
@@ -366,7 +382,7 @@ bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 // 20-22: ping-pong halves (k_gemm_pp.hip.h).  Default (-1): 12 for linear1 (5 when K < 512 or not a multiple of 128, 6 when not a multiple of 64), 7 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
 // every variant that was tried, including the ones no longer compiled in).
 template <class Epi>
-void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi_in, hipStream_t st, int hhd = 32) {
+int gemm_variant(int F, int K) {
     static const int forced_all = tune_int("LSL_GEMM", -1);
     static const int forced_1 = tune_int("LSL_GEMM1", -1), forced_2 = tune_int("LSL_GEMM2", -1);  // per GEMM: linear1 / linear2
     const int forced_one = std::is_same<Epi, EpiLinear2>::value ? forced_2 : forced_1;
@@ -374,10 +390,23 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
     const int ragged_variant = std::is_same<Epi, EpiLinear2>::value && K % 64 == 0 ? 11 : 10;  // measured on the D = 384 / 128 models
-    const int variant = forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 ? 12 : K % 64 == 0 ? 5 : 6));
+    return forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 ? 12 : K % 64 == 0 ? 5 : 6));
+}
+
+// linear2 can also write the next sub-block's LayerNorm + modulate (EpiLinear2::finish_rows) when it runs as the persistent
+// row-owner kernel over whole rows of D = 256 or 512 features and the launch has at least as many token tiles as workgroups
+bool linear2_can_fuse_ln(int D, int N, int K2) {
+    static const int off = tune_int("LSL_LN_FUSE", 0) == 0;  // measured and rejected (k_gemm.hip.h: EpiLinear2): experiments builds only
+    if (off || D % 256 != 0 || gemm_variant<EpiLinear2>(D, K2) != 7 || K2 % 128 != 0) return false;
+    return gemm_rows_walk<256, 256, 2, 4, 64, 2, EpiPieces<EpiLinear2>>(D, N);
+}
+
+template <class Epi>
+void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi_in, hipStream_t st, int hhd = 32, bool rows = false) {
+    const int variant = gemm_variant<Epi>(F, K);
     static const int probe = tune_int("LSL_PROBE", 0);
     static const int stagger = tune_int("LSL_STAGGER", 0);
-    GemmArgs g{W, X, F, N, K, stagger, probe};
+    GemmArgs g{W, X, F, N, K, rows ? 1 : 0, stagger, probe};
     // LSL_NT bit 0: linear1 output, bit 1: linear2 residual update, bit 2: attention output, bit 3: LayerNorm+modulate output
     static const int nt = tune_int("LSL_NT", 3);
     Epi epi = epi_in;
@@ -516,15 +545,19 @@ void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream
 }
 
 // one ParallelMLPAttentionV2 sub-block on h (in place): LN+modulate -> linear1 -> attention -> linear2
+// a_ready: ws.a already holds this sub-block's LayerNorm + modulate (written by the previous sub-block's linear2); fuse_next: let this
+// sub-block's linear2 write the next one's when the launch allows it (*a_written reports whether it did)
 int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *mods, int mod_stride, int bc, int T, int L,
-              hipStream_t st) {
+              hipStream_t st, bool a_ready = false, bool fuse_next = false, bool *a_written = nullptr) {
     const lsl_model_desc &d = m->d;
     const lsl_block_weights &bw = m->blocks[bi];
     const int D = d.hidden, n = bc * T * L, layer = bi / 2, temporal = bi & 1;
     const float *mbase = mods + (size_t)layer * 6 * D + (temporal ? 3 * D : 0);  // shift, scale, gate
-    m->prof.begin(3, st);
-    DISPATCH_D(D, launch_ln_mod_t, ws.a, h, mbase, mbase + D, mod_stride, n, T * L, st);
-    m->prof.end(3, st);
+    if (!a_ready) {
+        m->prof.begin(3, st);
+        DISPATCH_D(D, launch_ln_mod_t, ws.a, h, mbase, mbase + D, mod_stride, n, T * L, st);
+        m->prof.end(3, st);
+    }
     m->prof.begin(0, st);
 
     const float premul = (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
@@ -565,8 +598,11 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
 
     m->prof.begin(1, st);
     if ((unsigned long long)n * (unsigned)(T * L) >= (1ull << 32)) return fail(-3, "pass too large for the trajectory arithmetic");
-    EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L, 0, magic_of(T * L)};
-    launch_gemm((const u16 *)bw.w2, ws.z, D, n, m->K2, e2, st);
+    const bool fuse = fuse_next && bi + 1 < 2 * d.depth && linear2_can_fuse_ln(D, n, m->K2);
+    const float *nbase = mods + (size_t)((bi + 1) / 2) * 6 * D + (((bi + 1) & 1) ? 3 * D : 0);  // next sub-block: shift, scale
+    EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L, 0, magic_of(T * L), fuse ? ws.a : nullptr, nbase, nbase + D};
+    launch_gemm((const u16 *)bw.w2, ws.z, D, n, m->K2, e2, st, 32, fuse);
+    if (a_written) *a_written = fuse;
     m->prof.end(1, st);
     LSL_CHECK_LAUNCH("block");
     return 0;
@@ -590,9 +626,12 @@ int run_eval(lsl_model *m, const Workspace &ws, float *x, float *out, const floa
     if (d.normalize) { DISPATCH_D(D, launch_ln_inplace_t, ws.h, n, 1e-5f, st); }
     m->prof.end(5, st);
     LSL_CHECK_LAUNCH("embed");
+    bool a_ready = false;  // the first sub-block of an evaluation runs the standalone LayerNorm; later ones get `a` from the previous linear2
     for (int bi = 0; bi < 2 * d.depth; ++bi) {
-        rc = run_block(m, ws, bi, ws.h, ws.mods, mod_stride, bc, T, L, st);
+        bool wrote = false;
+        rc = run_block(m, ws, bi, ws.h, ws.mods, mod_stride, bc, T, L, st, a_ready, true, &wrote);
         if (rc) return rc;
+        a_ready = wrote;
     }
     const float *fm = ws.mods + (size_t)d.depth * 6 * D;  // adaLN: shift, scale
     m->prof.begin(4, st);
