@@ -61,12 +61,26 @@ __global__ void k_time_features(float *out, const float *t_ptr, float t_scalar, 
     out[b * 256 + 128 + k] = sinf(a);
 }
 
+// The same features for the rows (step s, trajectory b) of several sampler steps at once (k_resident.hip.h computes the modulation
+// tables of a whole group of state updates before its single launch): row = s * rows_per_step + b, time = t[s].
+struct StepTimes {
+    float t[48];
+};
+__global__ void k_time_features_steps(float *out, StepTimes st, int n_steps, int rows_per_step, const float *freqs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_steps * rows_per_step * 128) return;
+    const int row = i >> 7, k = i & 127;
+    const float a = 1000.0f * st.t[row / rows_per_step] * freqs[k];
+    out[row * 256 + k] = cosf(a);
+    out[row * 256 + 128 + k] = sinf(a);
+}
+
 // ---------------------------------------------------------------------------------------------------
-// out[b][o] = post(sum_i W[o][i] * pre(in[b][i]) + bias[o] + add[b][o]); one wave per output feature,
+// out[b][o] = post(sum_i W[o][i] * pre(in[b][i]) + bias[o] + add[b % add_mod][o]) (add_mod = 0: add[b]); one wave per output feature,
 // the weight row stays in registers while the wave walks the batch.  I <= 512.
 template <bool PRE_SILU, bool POST_SILU>
 __global__ void __launch_bounds__(256) k_dense_rows(float *out, const float *in, const float *W, const float *bias,
-                                                    const float *add, int rows, int I, int O, int add_stride) {
+                                                    const float *add, int rows, int I, int O, int add_stride, int add_mod) {
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= O) return;
@@ -91,7 +105,7 @@ __global__ void __launch_bounds__(256) k_dense_rows(float *out, const float *in,
         s = wave_sum(s);
         if (lane == 0) {
             s += bo;
-            if (add) s += add[(size_t)b * add_stride + o];
+            if (add) s += add[(size_t)(add_mod ? b % add_mod : b) * add_stride + o];
             if (POST_SILU) s = silu(s);
             out[(size_t)b * O + o] = s;
         }
@@ -105,7 +119,7 @@ __global__ void __launch_bounds__(256) k_dense_rows(float *out, const float *in,
 // rows serially and took 40 of 60 ms per sampling call of the pedestrian model at 1280 rows.
 template <bool PRE_SILU, bool POST_SILU>
 __global__ void __launch_bounds__(256) k_dense_tiled(float *out, const float *in, const float *W, const float *bias,
-                                                     const float *add, int rows, int I, int O, int add_stride) {
+                                                     const float *add, int rows, int I, int O, int add_stride, int add_mod) {
     __shared__ __attribute__((aligned(16))) float As[16][64 + 4];
     __shared__ __attribute__((aligned(16))) float Ws[16][64 + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -145,7 +159,7 @@ __global__ void __launch_bounds__(256) k_dense_tiled(float *out, const float *in
             const int o = o0 + 4 * tx + j;
             if (o >= O) continue;
             float v = acc[i][j] + bias[o];
-            if (add) v += add[(size_t)b * add_stride + o];
+            if (add) v += add[(size_t)(add_mod ? b % add_mod : b) * add_stride + o];
             if (POST_SILU) v = silu(v);
             out[(size_t)b * O + o] = v;
         }

@@ -20,6 +20,7 @@
 #include "k_attn.hip.h"
 #include "k_gemm.hip.h"
 #include "k_small.hip.h"
+#include "k_resident.hip.h"
 #ifdef LSL_EXPERIMENTS  // measured-and-rejected GEMM structures, built only by tools/build_experiments.sh (never in the product library)
 #include "experiments/k_gemm_pp.hip.h"
 #include "experiments/k_gemm_drain.hip.h"
@@ -480,18 +481,18 @@ void launch_attention_t(const AttnArgs &a, hipStream_t st) {
 
 template <bool PRE, bool POST>
 void launch_dense(float *out, const float *in, const float *W, const float *bias, const float *add, int rows, int I, int O,
-                  int add_stride, hipStream_t st, bool single = false) {
+                  int add_stride, hipStream_t st, bool single = false, int add_mod = 0) {
     // The choice must not depend on the BATCH: the two kernels sum k in different orders, and a trajectory's result has to be the
     // same bits whatever batch it is sampled in (K-sample batching, sharding, pass size).  `single` marks the calls that have one
     // row by construction (the sampler's shared time without class conditioning: one conditioning vector for any batch); they
     // take the wave-per-output kernel (a coalesced GEMV, 8x faster at one row than the 64-row tile kernel).
     if (single && rows == 1 && I <= 512)
-        hipLaunchKernelGGL((k_dense_rows<PRE, POST>), dim3((O + 3) / 4), dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride);
+        hipLaunchKernelGGL((k_dense_rows<PRE, POST>), dim3((O + 3) / 4), dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride, add_mod);
     else if (I % 4 == 0)
         hipLaunchKernelGGL((k_dense_tiled<PRE, POST>), dim3((O + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, out, in, W, bias, add, rows,
-                           I, O, add_stride);
+                           I, O, add_stride, add_mod);
     else
-        hipLaunchKernelGGL((k_dense_rows<PRE, POST>), dim3((O + 3) / 4), dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride);
+        hipLaunchKernelGGL((k_dense_rows<PRE, POST>), dim3((O + 3) / 4), dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride, add_mod);
 }
 
 // ---- pieces of one evaluation ----------------------------------------------------------------------
@@ -652,6 +653,114 @@ int prepare_pass(lsl_model *m, const Workspace &ws, const float *x_cond, const i
     return 0;
 }
 
+// ---- trajectory-resident path (k_resident.hip.h): models whose whole trajectory fits one workgroup's LDS ----------------------
+// The choice depends on the MODEL and on T*L only, never on the batch: a trajectory's bits are the same in any batch / shard / pass.
+bool resident_ok(const lsl_model *m, int T, int L) {
+    static const int off = env_int("LSL_RESIDENT", 1) == 0;  // documented runtime switch: 0 = always the general path
+    const lsl_model_desc &d = m->d;
+    return !off && d.hidden == RES_D && d.heads == RES_H && d.head_dim == RES_HD && d.head_dim_pad == RES_HD && d.mlp_dim == RES_M &&
+           d.in_dim <= RES_MAX_C && d.in_dim % 4 == 0 && 2 * d.depth <= RES_MAX_BLOCKS && (long)T * L <= 48 && T + L <= 64;
+}
+
+struct ResWorkspace {
+    float *cond_emb, *yemb, *tfeat, *hid, *vec, *mods;
+    int steps_per_launch;
+    size_t bytes;
+};
+ResWorkspace carve_resident(const lsl_model *m, char *base, int B, int T, int L, bool have_y) {
+    const size_t n = (size_t)B * T * L, D = m->d.hidden;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align_up(bytes, 256);
+        return p;
+    };
+    ResWorkspace ws;
+    const size_t rows = have_y ? (size_t)B : 1;
+    // modulation tables of a whole group of state updates are computed before the group's single launch: bound them to 256 MiB
+    size_t spl = ((size_t)256 << 20) / (rows * m->MODW * 4);
+    ws.steps_per_launch = (int)std::max<size_t>(1, std::min<size_t>(spl, RES_MAX_STEPS));
+    const size_t rt = rows * ws.steps_per_launch;
+    ws.cond_emb = (float *)take(n * D * 4);
+    ws.yemb = (float *)take((size_t)B * D * 4);
+    ws.tfeat = (float *)take(rt * 256 * 4);
+    ws.hid = (float *)take(std::max(rt, (size_t)B) * D * 4);
+    ws.vec = (float *)take(rt * D * 4);
+    ws.mods = (float *)take(rt * m->MODW * 4);
+    ws.bytes = off;
+    return ws;
+}
+
+template <int NNT>
+void launch_resident(const ResArgs &a, int B, int T, int L, hipStream_t st) {
+    auto kern = k_resident<NNT>;
+    const size_t lds = ResLds<NNT>::bytes(T, L);
+    LSL_ALLOW_LDS(kern, (size_t)163840);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(RES_NTHR), lds, st, a);
+}
+
+int resident_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int n_steps, const float *noise, uint64_t seed, uint64_t elem_offset,
+                    float *trace, void *workspace, hipStream_t st) {
+    const lsl_model_desc &d = m->d;
+    const lsl_weights &w = m->w;
+    const int B = io->B, T = io->T, L = io->L, n_t = T * L, D = d.hidden;
+    const bool have_y = io->y != nullptr;
+    const ResWorkspace ws = carve_resident(m, (char *)workspace, B, T, L, have_y);
+    const int rows = have_y ? B : 1;
+    launch_embed<0>(ws.cond_emb, io->x_cond, w.cond_w, w.cond_b, w.x_in_b, w.mask_emb, io->mask, nullptr, B * n_t, d.in_dim, D, st);
+    LSL_CHECK_LAUNCH("cond_embed");
+    if (have_y) {
+        launch_dense<false, true>(ws.hid, io->y, w.vec_w1, w.vec_b1, nullptr, B, d.vec_in_dim, D, 0, st);
+        launch_dense<false, false>(ws.yemb, ws.hid, w.vec_w2, w.vec_b2, nullptr, B, D, D, 0, st);
+        LSL_CHECK_LAUNCH("vec_in");
+    }
+    ResArgs a;
+    a.cond_emb = ws.cond_emb;
+    a.x = io->x;
+    a.mods = ws.mods;
+    a.mods_step_stride = (long)rows * m->MODW;
+    a.mods_traj_stride = have_y ? m->MODW : 0;
+    a.x_in_w = w.x_in_w;
+    a.out_w = w.out_w;
+    a.out_b = w.out_b;
+    a.noise = noise;
+    a.noise_step_stride = (long)B * n_t * d.in_dim;
+    a.seed = seed;
+    a.elem_offset = elem_offset;
+    a.trace = trace;
+    a.trace_step_stride = (long)B * n_t * d.in_dim;
+    a.n_t = n_t; a.T = T; a.L = L; a.C = d.in_dim; a.depth = d.depth; a.normalize = d.normalize;
+    a.theta = d.theta;
+    a.skip = tune_int("LSL_RES_SKIP", 0);
+    a.q_premul = (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
+    for (int bi = 0; bi < 2 * d.depth; ++bi) {
+        const lsl_block_weights &bw = m->blocks[bi];
+        a.blk[bi] = ResBlock{(const u16 *)bw.w1, bw.b1, bw.qs, bw.ks, (const u16 *)bw.w2, bw.b2};
+    }
+    for (int s0 = 0; s0 < n_steps; s0 += ws.steps_per_launch) {
+        const int ns = std::min(ws.steps_per_launch, n_steps - s0);
+        StepTimes tt;
+        for (int s = 0; s < ns; ++s) {
+            tt.t[s] = steps[s0 + s].t;
+            a.step[s] = make_float4(steps[s0 + s].t, steps[s0 + s].ax, steps[s0 + s].am, steps[s0 + s].aw);
+        }
+        const int rt = ns * rows;
+        // conditioning vector -> modulation tables of the group's steps (latent_si_v31.py:176-178, mmdit.py:184-197); the tiled kernel
+        // is used for any row count, so a trajectory's tables do not depend on the batch it is sampled in
+        hipLaunchKernelGGL(k_time_features_steps, dim3((rt * 128 + 255) / 256), dim3(256), 0, st, ws.tfeat, tt, ns, rows, w.time_freqs);
+        launch_dense<false, true>(ws.hid, ws.tfeat, w.time_w1, w.time_b1, nullptr, rt, 256, D, 0, st);
+        launch_dense<false, false>(ws.vec, ws.hid, w.time_w2, w.time_b2, have_y ? ws.yemb : nullptr, rt, D, D, D, st, false, have_y ? B : 0);
+        launch_dense<true, false>(ws.mods, ws.vec, w.mod_w, w.mod_b, nullptr, rt, D, m->MODW, 0, st);
+        LSL_CHECK_LAUNCH("modulation");
+        a.step0 = (unsigned)s0;
+        a.n_steps = ns;
+        if (n_t <= 32) launch_resident<2>(a, B, T, L, st);
+        else launch_resident<3>(a, B, T, L, st);
+        LSL_CHECK_LAUNCH("k_resident");
+    }
+    return 0;
+}
+
 int check_call(const lsl_model *m, const lsl_io *io, size_t ws_bytes, void *ws, int *chunk_out) {
     if (!m || !io) return fail(-1, "null model or io");
     if (!m->has_weights) return fail(-2, "weights not set");
@@ -660,7 +769,8 @@ int check_call(const lsl_model *m, const lsl_io *io, size_t ws_bytes, void *ws, 
     if ((io->y != nullptr) != (m->d.vec_in_dim > 0) && io->y != nullptr) return fail(-3, "y given but the model has no vec_in");
     if ((size_t)io->T * io->L > (1u << 24)) return fail(-3, "T*L too large");
     const int chunk = default_chunk(m, io->B, io->T, io->L);
-    const size_t need = carve(m, nullptr, chunk, io->T, io->L).bytes * n_lanes();
+    size_t need = carve(m, nullptr, chunk, io->T, io->L).bytes * n_lanes();
+    if (resident_ok(m, io->T, io->L)) need = std::max(need, carve_resident(m, nullptr, io->B, io->T, io->L, m->d.vec_in_dim > 0).bytes);
     if (!ws || ws_bytes < need) return fail(-4, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
     *chunk_out = chunk;
     return 0;
@@ -801,7 +911,9 @@ int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
 
 size_t lsl_workspace_bytes(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
     if (!m || B <= 0 || T <= 0 || L <= 0) return 0;
-    return carve(m, nullptr, default_chunk(m, B, T, L), T, L).bytes * n_lanes();
+    size_t need = carve(m, nullptr, default_chunk(m, B, T, L), T, L).bytes * n_lanes();
+    if (resident_ok(m, T, L)) need = std::max(need, carve_resident(m, nullptr, B, T, L, m->d.vec_in_dim > 0).bytes);
+    return need;
 }
 
 int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspace_bytes, void *stream) try {
@@ -841,6 +953,8 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
         for (int s = n_noise < 0 ? 0 : n_noise; s < n_steps; ++s)
             if (steps[s].aw != 0.0f) return fail(-3, "step %d needs noise but only %d slices were given", s, n_noise);
     hipStream_t st = (hipStream_t)stream;
+    if (resident_ok(m, io->T, io->L) && m->prof.kernel < 0)  // small trajectories: the whole loop in one launch per group of updates
+        return resident_sample(m, io, steps, n_steps, noise, seed, elem_offset, trace, workspace, st);
     // hipGraph replay (opt-in).  LSL_GRAPH: 0 off (default), 1 for launch-bound calls (at most 64 Ki tokens per pass and 4096 launches) whose
     // arguments repeat, 2 for every call of at most 4096 launches: the first appearance of an argument set runs eagerly (it also initialises
     // the per-kernel attributes), the second is captured, later ones are replayed.  Measured on MI355X (tools/latency_small_batch.py): a
