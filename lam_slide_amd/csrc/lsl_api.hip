@@ -909,6 +909,11 @@ int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
     return default_chunk(m, B, T, L);
 }
 
+int32_t lsl_sampler_path(const lsl_model *m, int32_t T, int32_t L) {
+    if (!m || T <= 0 || L <= 0) return -1;
+    return resident_ok(m, T, L) ? 1 : 0;
+}
+
 size_t lsl_workspace_bytes(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
     if (!m || B <= 0 || T <= 0 || L <= 0) return 0;
     size_t need = carve(m, nullptr, default_chunk(m, B, T, L), T, L).bytes * n_lanes();

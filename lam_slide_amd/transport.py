@@ -303,6 +303,7 @@ class Sampler:
         self.calls = 0
         self.last_seed: Optional[int] = None  # stream seed of the most recent fused call
         self.last_path: Optional[str] = None
+        self.last_kernels: Optional[str] = None  # "general" | "resident" (lsl_sampler_path) after a fused call
         self.elem_offset = 0  # global element index of this rank's first state element (device noise stream)
 
     def next_call_seed(self) -> int:
@@ -411,6 +412,7 @@ class Sampler:
                                       trace.data_ptr() if trace is not None else None, ws.data_ptr(), ws.numel(), stream))
         net.last_path = "hip"
         self.last_path = "fused"
+        self.last_kernels = "resident" if lib.lsl_sampler_path(net._handle, io.T, io.L) == 1 else "general"
         del keep
         if net.graph_replay_enabled():
             x = x.clone()  # the persistent buffer is overwritten by the next call

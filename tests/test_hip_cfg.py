@@ -236,3 +236,96 @@ def test_forward_argument_checks_on_device(dev):
         net(x, torch.full((3,), 0.3, device=dev), xc.cpu(), m)
     with pytest.raises(ValueError):
         net(x, torch.full((2,), 0.3, device=dev), xc, m)
+
+
+RESIDENT_CASES = {
+    # name: (T, L, C, vec_in_dim, normalize, depth, method)      all with hidden 128, 4 heads of 32, mlp_ratio 2 (the pedestrian family)
+    "ped_like_T20_L2": (20, 2, 32, 256, True, 6, "ODE"),          # temporal attention on MFMA (S = 20), spatial per lane (S = 2)
+    "T5_L6_two_tiles": (5, 6, 32, None, False, 2, "ODE"),         # 30 tokens: two 16-token tiles, both axes per lane
+    "T12_L4_C16": (12, 4, 16, 24, False, 2, "SDE"),               # 48 tokens (three full tiles), narrow state, stored noise + trajectory
+    "T3_L1_C8": (3, 1, 8, None, True, 1, "ODE"),                  # S = 1 along the spatial axis
+    "T17_L2_sde_tweedie": (17, 2, 32, None, False, 3, "SDE2"),    # odd T: padded key tile of the MFMA attention masked
+}
+
+
+@pytest.mark.parametrize("name", sorted(RESIDENT_CASES))
+def test_trajectory_resident_kernel_against_oracle(name, dev):
+    """csrc/k_resident.hip.h (one workgroup per trajectory, every state update in one launch) against the oracle: ODE and SDE step tables,
+    stored noise, kept trajectory, class vector, normalize, padded token tiles, both attention forms.  The path must actually be taken."""
+    from lam_slide_amd import CreateTransport, Sampler
+    from oracle import harness, transport as otr
+    T, L, C, V, norm, depth, method = RESIDENT_CASES[name]
+    kw = dict(depth=depth, in_dim=C, hidden_size=128, num_heads=4, mlp_ratio=2, normalize=norm)
+    if V:
+        kw["vec_in_dim"] = V
+    net, sh, p = _net(kw, 31, dev)
+    B = 5
+    g = torch.Generator().manual_seed(41)
+    lat, init = torch.randn(B, T, L, C, generator=g), torch.randn(B, T, L, C, generator=g)
+    y = torch.randn(B, V, generator=g) if V else None
+    xc, m = harness.setup_conditioning(lat, (0, max(1, T // 3)), True)
+    mk = {"x_cond": xc.to(dev), "x_cond_mask": m.to(dev)}
+    if y is not None:
+        mk["y"] = y.to(dev)
+    s = Sampler(CreateTransport("GVP", "data")(), fused=True, keep_trajectory=method != "ODE")
+    if method == "ODE":
+        skw = {"sampling_method": "euler", "num_steps": 9}
+        got = s.get_sample_fn("ODE", skw)(init.to(dev), net.forward, **mk)[-1]
+        want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, m, y, "ODE", skw)
+        assert s.last_kernels == "resident"
+        parity(f"resident.{name}", rel_l2(got.cpu(), want), {"ped_like_T20_L2": 1e-3}.get(name, 4e-4))
+    else:
+        n = 7
+        form, last = ("linear", "Mean") if method == "SDE" else ("sigma", "Tweedie")
+        noise = torch.randn(n - 1, B, T, L, C, generator=g)
+        res = s.sample_sde(diffusion_form=form, last_step=last, num_steps=n, noise=noise.to(dev))(init.to(dev), net.forward, **mk)
+        assert s.last_kernels == "resident" and len(res) == n
+
+        def model(xt, t, **kw_):
+            from oracle import latent_net
+            return latent_net.forward(p, sh, xt, t.to(xt.dtype), **kw_)
+
+        mko = {"x_cond": xc, "x_cond_mask": m}
+        if y is not None:
+            mko["y"] = y
+        xs = otr.sample_sde(otr.Transport("GVP", "data"), init, model, noise=list(noise), diffusion_form=form, last_step=last, num_steps=n,
+                            single_eval=True, **mko)
+        parity(f"resident.{name}.final", rel_l2(res[-1].cpu(), xs[-1]), 7e-4)
+        parity(f"resident.{name}.mid", rel_l2(res[3].cpu(), xs[3]), 3e-4)
+    # a trajectory's bits do not depend on the batch it is sampled in (the path choice does not depend on B either)
+    s1 = Sampler(CreateTransport("GVP", "data")(), fused=True)
+    mk1 = {k: v[3:4] for k, v in mk.items()}
+    if method == "ODE":
+        alone = s1.get_sample_fn("ODE", skw)(init[3:4].to(dev), net.forward, **mk1)[-1]
+        assert torch.equal(alone, got[3:4])
+    else:
+        alone = s1.sample_sde(diffusion_form=form, last_step=last, num_steps=n, noise=noise[:, 3:4].to(dev))(init[3:4].to(dev), net.forward, **mk1)[-1]
+        assert torch.equal(alone, res[-1][3:4])
+
+
+def test_resident_kernel_many_updates_and_device_noise(dev):
+    """More state updates than one launch of the resident kernel holds (48): the groups chain through the state in HBM; and the device
+    noise stream (Philox) of the resident path is shard-invariant like the general path's."""
+    from lam_slide_amd import CreateTransport, Sampler
+    from oracle import harness, transport as otr
+    kw = dict(depth=2, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2)
+    net, sh, p = _net(kw, 7, dev)
+    B, T, L = 3, 10, 2
+    g = torch.Generator().manual_seed(3)
+    lat, init = torch.randn(B, T, L, 32, generator=g), torch.randn(B, T, L, 32, generator=g)
+    xc, m = harness.setup_conditioning(lat, (0, 3), True)
+    mk = {"x_cond": xc.to(dev), "x_cond_mask": m.to(dev)}
+    skw = {"sampling_method": "euler", "num_steps": 61}   # 60 updates = 48 + 12
+    s = Sampler(CreateTransport("GVP", "data")(), fused=True)
+    got = s.get_sample_fn("ODE", skw)(init.to(dev), net.forward, **mk)[-1]
+    assert s.last_kernels == "resident"
+    want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, m, None, "ODE", skw)
+    parity("resident.60_updates", rel_l2(got.cpu(), want), 6e-4)
+
+    def run(lo, hi):
+        sd = Sampler(CreateTransport("GVP", "data")(), fused=True, seed=5)
+        sd.elem_offset = lo * T * L * 32
+        return sd.get_sample_fn("SDE", {"num_steps": 5})(init[lo:hi].to(dev), net.forward, **{k: v[lo:hi] for k, v in mk.items()})[-1]
+
+    full = run(0, 3)
+    assert torch.equal(full, torch.cat([run(0, 1), run(1, 3)])) and torch.isfinite(full).all()
