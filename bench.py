@@ -239,7 +239,10 @@ def run_rank(args) -> int:
 
     for _ in range(args.warmup):
         one_step()
-    if rank == 0 and not stub:
+    # small-trajectory models run the trajectory-resident kernel (one launch per group of state updates, no per-kernel classes to
+    # bracket): the per-kernel HIP-event profiler would force the general path, so it stays off for them
+    resident = (not stub) and lib.lsl_sampler_path(net._handle, T, L) == 1
+    if rank == 0 and not stub and not resident:
         _lib.check(lib.lsl_profile_enable(net._handle, args.profile_kernel, 4096))
     fence()
     t0 = time.perf_counter()
@@ -290,8 +293,10 @@ def run_rank(args) -> int:
         return 0
 
     total_ms, launches = C.c_double(), C.c_int32()
-    _lib.check(lib.lsl_profile_read(net._handle, C.byref(total_ms), C.byref(launches)))
-    lib.lsl_profile_enable(net._handle, -1, 0)
+    if not resident:
+        _lib.check(lib.lsl_profile_read(net._handle, C.byref(total_ms), C.byref(launches)))
+        lib.lsl_profile_enable(net._handle, -1, 0)
+    out["config"]["kernels"] = "trajectory-resident (k_resident)" if resident else "general"
     f_eval = flops_per_eval_per_traj(kw, T, L)
     ws_bytes = lib.lsl_workspace_bytes(net._handle, B, T, L)
     pass_size = lib.lsl_pass_size(net._handle, B, T, L)
@@ -300,11 +305,17 @@ def run_rank(args) -> int:
     block_evals = 2 * kw["depth"] * n_evals * args.steps          # launches of each block kernel per pass
     launches_total = passes * block_evals
     tok_total = B * T * L
+    if resident:  # the whole call is (groups of) one kernel: its rate is the whole-path rate
+        launches_total = 1
+        args.profile_kernel = -2
     kname, kflops_total = {
         0: ("k_gemm_glds<EpiLinear1> (linear1 + QK-norm/RoPE/GELU epilogue)", 2.0 * tok_total * D * (3 * D + M) * block_evals),
         1: ("k_gemm_glds<EpiLinear2> (linear2 + gate/residual epilogue)", 2.0 * tok_total * (D + M) * D * block_evals),
         2: ("k_attention", 4.0 * tok_total * D * (L + T) / 2 * block_evals),
     }.get(args.profile_kernel, (f"kernel class {args.profile_kernel}", 0.0))
+    if resident:
+        kname, kflops_total = "k_resident (all state updates of a trajectory in one workgroup)", float(f_eval) * n_evals * B
+        total_ms.value, launches.value = dt / args.steps * 1e3, 1
     avg_ms = total_ms.value / max(1, launches.value)
     flops_per_launch = kflops_total / max(1, launches_total)      # algorithmic FLOPs of one launch
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 and kflops_total else None
@@ -340,7 +351,7 @@ def run_rank(args) -> int:
         torch.cuda.synchronize()
         return (time.perf_counter() - t1) / reps
 
-    if args.breakdown:
+    if args.breakdown and not resident:
         breakdown = {}
         names = ["linear1", "linear2", "attention", "ln_modulate", "head_step", "embed", "modulation"]
         for kid, nm in enumerate(names):

@@ -13,13 +13,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define LDS_PTR(T) __attribute__((address_space(3))) T *
 
-// Timing probes (skip loads / MFMAs / epilogue phases: results WRONG) exist only in -DLSL_EXPERIMENTS builds made by tools/;
-// in the product library the test folds to 0 and no environment variable can reach them.
-#ifdef LSL_EXPERIMENTS
+// Timing probes (skip loads / MFMAs / epilogue phases: results WRONG when set).  The probe words are kernel ARGUMENTS; the host fills them
+// from LSL_PROBE / LSL_RES_SKIP only in -DLSL_EXPERIMENTS builds (tune_int in lsl_api.hip) and with a hard 0 in the product library,
+// so no environment variable can reach them there.  The run-time tests themselves stay in both builds on purpose: with them folded
+// away at compile time hipcc schedules the linear1 kernel into 256 VGPRs + 52 B of scratch (376 ms per cfg-2 step) instead of 231
+// VGPRs and no scratch (346 ms) - the never-taken branches bound how far it interleaves the epilogue with the main loop - and
+// keeping them makes the tools' A/B builds generate the same code as the product.
 #define LSL_PROBE(v, bit) ((v) & (bit))
-#else
-#define LSL_PROBE(v, bit) 0
-#endif
 
 // 32x32x16 bf16 MFMA, fp32 accumulate.  Operand maps (lane l: r = l & 31, hf = l >> 5):
 //   A[row r][k = 8 hf + j], B[k = 8 hf + j][col r], j = 0..7
