@@ -391,7 +391,7 @@ int gemm_variant(int F, int K) {
     // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
     const int ragged_variant = std::is_same<Epi, EpiLinear2>::value && K % 64 == 0 ? 11 : 10;  // measured on the D = 384 / 128 models
-    return forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 ? 12 : K % 64 == 0 ? 5 : 6));
+    return forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 ? 12 : 5));
 }
 
 // linear2 can also write the next sub-block's LayerNorm + modulate (EpiLinear2::finish_rows) when it runs as the persistent
@@ -428,9 +428,13 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
         case 11: return launch_gemm_glds<128, 128, 2, 2, 64, 2, false>(g, epi, st);
 #ifdef LSL_EXPERIMENTS
         case 13: return launch_gemm_glds<256, 128, 2, 2, 32, 2, true>(g, epi, st);
+        case 14: return launch_gemm_glds<256, 128, 2, 2, 64, 2, true>(g, epi, st);  // 4 waves, one per SIMD, 64-deep k-tiles, one workgroup per CU
 #endif
         case 15: return launch_gemm_glds<256, 256, 4, 4, 64, 2, false>(g, epi, st);
-        default: return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, epi, st);
+#ifdef LSL_EXPERIMENTS
+        case 6: return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, epi, st);
+#endif
+        default: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);  // (K is a multiple of 64: hidden sizes are)
     }
 }
 
