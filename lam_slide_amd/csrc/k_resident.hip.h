@@ -126,6 +126,21 @@ __device__ __forceinline__ void res_barrier() {
     asm volatile("" ::: "memory");
 }
 
+#ifdef LSL_EXPERIMENTS
+// phase clock of workgroup 0 / wave 0 (tools/resident_probe.py --stamps): cycles spent up to the barrier that ends each phase
+__device__ unsigned long long g_res_stamps[8];
+#define RES_STAMP(PHASE)                                                                  \
+    do {                                                                                  \
+        if (blockIdx.x == 0 && tid == 0) {                                                \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                 \
+            atomicAdd(&g_res_stamps[PHASE], now_ - stamp_t_);                             \
+            stamp_t_ = now_;                                                              \
+        }                                                                                 \
+    } while (0)
+#else
+#define RES_STAMP(PHASE) do {} while (0)
+#endif
+
 template <int NNT>
 __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
     using LO = ResLds<NNT>;
@@ -258,6 +273,9 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
         for (int ks = 0; ks < nks; ++ks) dst[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(p + 32 * ks));
     };
 
+#ifdef LSL_EXPERIMENTS
+    unsigned long long stamp_t_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int s = 0; s < A.n_steps; ++s) {
         // ---- embedding: h = x Wx^T + cond_emb (latent_si_v31.py:172), optional LayerNorm eps 1e-5 (:173-174) -------------------
         float wx[RES_MAX_C];  // this thread's column of the input projection (L1-resident; live only here: 256-VGPR budget)
@@ -287,6 +305,7 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
             layer_norm(0, 1e-5f, nullptr, nullptr, nullptr);
             res_barrier();
         }
+        RES_STAMP(4);
 
         for (int bi = 0; bi < nb; ++bi) {
             const ResBlock &B = A.blk[bi];
@@ -300,6 +319,7 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
             load_w(B.w1, D, wave * 32 + 16, 4, wA[1]);
             if (!LSL_PROBE(A.skip, 8)) layer_norm(1, 1e-6f, pb + RES_P_SHIFT, pb + RES_P_SCALE, nullptr);
             res_barrier();
+            RES_STAMP(0);
             // ---- linear1 (+ bias, QK-RMSNorm, RoPE, GELU): a[NP][128] x W1[640][128]^T -> qkv, z ---------------------------------
             // 20 pairs of 16-feature tiles (one 32-wide head, or 32 mlp features), pairs wave, wave + 8, wave + 16
             if (!LSL_PROBE(A.skip, 2)) {
@@ -381,6 +401,7 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
             bf16x8 w2f[12];
             load_w(B.w2, RES_K2, wave * 16, 12, w2f);
             res_barrier();
+            RES_STAMP(1);
             // ---- attention over the spatial (sequence (t), positions l) or temporal (sequence (l), positions t) axis ------------------
             const int S = temporal ? T : L, n_seq = temporal ? L : T, sstride = temporal ? L : 1, qbase_mul = temporal ? 1 : L;
             if (LSL_PROBE(A.skip, 1)) {
@@ -496,6 +517,7 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
                 }
             }
             res_barrier();
+            RES_STAMP(2);
             // ---- linear2 + gate * (.) + residual: z[NP][384] x W2[128][384]^T, h += gate (acc + b2)   (latent_si_v31.py:53,60) ------
             // 8 feature tiles of 16, one per wave
             if (!LSL_PROBE(A.skip, 4)) {
@@ -528,6 +550,7 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
             }
             par_commit(q + 1);
             res_barrier();
+            RES_STAMP(3);
         }
 
         // ---- output head (latent_si_v31.py:185-187) fused with the sampler's affine step -------------------------------------------
@@ -561,6 +584,7 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
         }
         if (s + 1 < A.n_steps) par_commit(qh + 1);
         res_barrier();
+        RES_STAMP(5);
     }
     for (int i = tid; i < n_t * C; i += NT) A.x[xoff + i] = xs[(i / C) * RES_MAX_C + (i % C)];
 }

@@ -913,6 +913,17 @@ int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
     return default_chunk(m, B, T, L);
 }
 
+#ifdef LSL_EXPERIMENTS
+// tools only: read and clear the phase clock of k_resident (cycles of workgroup 0 / wave 0 per phase)
+int lsl_debug_res_stamps(unsigned long long *out8) {
+    hipDeviceSynchronize();
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_res_stamps), sizeof(z)) != hipSuccess) return fail(-10, "stamps");
+    hipMemcpyToSymbol(HIP_SYMBOL(g_res_stamps), z, sizeof(z));
+    return 0;
+}
+#endif
+
 int32_t lsl_sampler_path(const lsl_model *m, int32_t T, int32_t L) {
     if (!m || T <= 0 || L <= 0) return -1;
     return resident_ok(m, T, L) ? 1 : 0;

@@ -33,4 +33,14 @@ for B, ns in ((20, 11), (20, 2), (1280, 11), (1280, 2)):
     for _ in range(20):
         drv.sample_latents(lat, y=y, init=init)
     torch.cuda.synchronize()
+    if "--stamps" in sys.argv:
+        import ctypes as C
+        lib = _lib.load()
+        buf = (C.c_ulonglong * 8)()
+        lib.lsl_debug_res_stamps(buf)  # clear
+        drv.sample_latents(lat, y=y, init=init)
+        lib.lsl_debug_res_stamps(buf)
+        tot = sum(buf)
+        names = ["LayerNorm", "linear1", "attention", "linear2", "embed", "head", "-", "-"]
+        print("  phase cycles (workgroup 0, wave 0): " + "  ".join(f"{n} {v} ({100 * v / tot:.0f} %)" for n, v in zip(names, buf) if v))
     print(f"LSL_RES_SKIP={os.environ.get('LSL_RES_SKIP', '0'):>2}  B={B:5d}: {(time.perf_counter() - t0) / 20 * 1e3:7.3f} ms per {ns - 1}-update call")
