@@ -87,8 +87,10 @@ __device__ __forceinline__ float gelu_fast(float x) {
     p = fmaf(t, p, 0.5f * -0.284496736f);
     p = fmaf(t, p, 0.5f * 0.254829592f);
     const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * (x * x));
-    float relu;  // fmaxf() costs a second v_max (input canonicalisation); NaN still propagates through the fma below
-    asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(x));
+    // max(x, 0) as ONE instruction the compiler knows (v_med3_f32 x, 0, +inf): fmaxf() costs a second v_max (input canonicalisation), and
+    // an inline-asm v_max is invisible to the hazard recognizer - placed right behind the MFMA that produces x it read the accumulator
+    // before the matrix pipe had written it (no hardware interlock, no s_nop: wrong and timing-dependent results, found in k_resident)
+    const float relu = __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
     return fmaf(-ax, p * t * e, relu);
 }
 

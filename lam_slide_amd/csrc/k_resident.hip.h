@@ -32,16 +32,42 @@ constexpr int RES_D = 128, RES_H = 4, RES_HD = 32, RES_HHD = 128, RES_M = 256, R
 constexpr int RES_MAX_STEPS = 48, RES_MAX_BLOCKS = 16, RES_MAX_C = 32;
 constexpr int RES_HS = 132;        // h row stride in floats (528 B: the 16 token rows of a tile fall on distinct 16-byte LDS slots)
 constexpr int RES_QS = 392;        // qkv row stride in bf16 (784 B, same reason for the per-lane row reads of the attention)
+constexpr int RES_XS = 36;         // state row stride in floats (144 B: conflict-free 16-byte reads of the embedding's token operand)
 // Small parameters of one stage (= one sub-block, or the output head), staged in LDS one stage ahead so that no phase waits on an L2
 // round trip for them: [b1 640 | qs 32 | ks 32 | b2 128 | shift 128 | scale 128 | gate 128]; the head stage holds [shift 128 | scale 128]
 constexpr int RES_PAR = 1280, RES_P_QS = 640, RES_P_KS = 672, RES_P_B2 = 704, RES_P_SHIFT = 832, RES_P_SCALE = 960, RES_P_GATE = 1088;
 
 struct ResBlock {
-    const u16 *w1;  // [640 (padded)][128] bf16
-    const float *b1, *qs, *ks;
-    const u16 *w2;  // [128 (padded)][384] bf16
-    const float *b2;
+    const u16 *w1;  // linear1 weights in FRAGMENT order (k_res_pack): [40 tiles][4 k-steps][64 lanes][8] bf16
+    const u16 *w2;  // linear2 weights, same order: [8 tiles][12 k-steps][64 lanes][8]
 };
+constexpr size_t RES_W1_ELEMS = (size_t)640 * 128, RES_W2_ELEMS = (size_t)128 * 384;
+// Once per call (one launch): (a) the GEMM weights of every block are re-ordered into the MFMA A-fragment order, so that each of the
+// kernel's weight loads (one k-step of one 16-feature tile, 16 bytes per lane) reads 1 KiB CONTIGUOUS - measured 2.6x the load rate of
+// the row-major form, whose 64 lanes touch 16 rows x 64 bytes (a CU takes ~55 cycles per such instruction, ~24 per contiguous one), and
+// the weight stream is what bounds this kernel; (b) the small per-block parameters are gathered into one row per block
+// [b1 640 | qs 32 | ks 32 | b2 128], so that the one-stage-ahead parameter staging is one base pointer + lane offset.
+struct ResPack {
+    const u16 *w1[RES_MAX_BLOCKS], *w2[RES_MAX_BLOCKS];  // row-major [F pad][K] (packing.py)
+    const float *b1[RES_MAX_BLOCKS], *qs[RES_MAX_BLOCKS], *ks[RES_MAX_BLOCKS], *b2[RES_MAX_BLOCKS];
+};
+__global__ void __launch_bounds__(256) k_res_pack(u16 *wout, float *pout, ResPack P) {
+    const int bi = blockIdx.x, job = blockIdx.y, tid = threadIdx.x;  // job 0..39: linear1 tile, 40..47: linear2 tile, 48: parameters
+    u16 *wb = wout + (size_t)bi * (RES_W1_ELEMS + RES_W2_ELEMS);
+    if (job < 48) {
+        const bool second = job >= 40;
+        const int tile = second ? job - 40 : job, K = second ? RES_K2 : RES_D, nks = K / 32;
+        const u16 *src = second ? P.w2[bi] : P.w1[bi];
+        u16 *dst = (second ? wb + RES_W1_ELEMS : wb) + (size_t)tile * 16 * K;
+        for (int i = tid; i < nks * 64; i += 256) {
+            const int ks = i >> 6, lane = i & 63;
+            *reinterpret_cast<u32x4 *>(dst + (size_t)i * 8) = *reinterpret_cast<const u32x4 *>(src + (size_t)(tile * 16 + (lane & 15)) * K + 32 * ks + 8 * (lane >> 4));
+        }
+    } else {
+        for (int i = tid; i < RES_P_SHIFT; i += 256)
+            pout[(size_t)bi * RES_P_SHIFT + i] = i < RES_P_QS ? P.b1[bi][i] : i < RES_P_KS ? P.qs[bi][i - RES_P_QS] : i < RES_P_B2 ? P.ks[bi][i - RES_P_KS] : P.b2[bi][i - RES_P_B2];
+    }
+}
 
 struct ResArgs {
     float *x;                 // [B][n_t][C] state, updated in place
@@ -49,6 +75,7 @@ struct ResArgs {
     const float *mods;        // [n_steps][rows][MODW] modulation tables of every step of this launch (rows = B, or 1 when shared)
     long mods_step_stride;    // floats between steps
     int mods_traj_stride;     // floats between trajectories (0: one shared row)
+    const float *blkpar;      // [2 depth][RES_P_SHIFT] (k_res_pack)
     const float *x_in_w;      // [D][C]
     const float *out_w, *out_b;  // [C][D], [C]
     const float *noise;       // [.. steps][B*n_t*C] or NULL (device Philox)
@@ -58,7 +85,7 @@ struct ResArgs {
     float *trace;             // optional [.. steps][B*n_t*C]
     long trace_step_stride;
     int n_t, T, L, C, depth, normalize, n_steps;
-    int skip;                 // -DLSL_EXPERIMENTS builds only (LSL_RES_SKIP, results WRONG): 1 attention, 2 linear1, 4 linear2, 8 LayerNorm
+    int skip;                 // -DLSL_EXPERIMENTS builds only (LSL_RES_SKIP, results WRONG): 1 attention, 4 linear2, 8 LayerNorm
     float theta, q_premul;
     float4 step[RES_MAX_STEPS];  // (t, ax, am, aw) of lsl_step
     ResBlock blk[RES_MAX_BLOCKS];
@@ -71,14 +98,22 @@ struct ResLds {
     static constexpr size_t a = h + (size_t)NP * RES_HS * 4;              // bf16 [NP][128], 16-byte chunks XOR-swizzled by the row
     static constexpr size_t qkv = a + (size_t)NP * RES_D * 2;             // bf16 [NP][RES_QS]
     static constexpr size_t z = qkv + (size_t)NP * RES_QS * 2;            // bf16 [NP][384], chunks swizzled inside each 256-byte group
-    static constexpr size_t x = z + (size_t)NP * RES_K2 * 2;              // fp32 [NP][32]
-    static constexpr size_t wo = x + (size_t)NP * RES_MAX_C * 4;          // fp32 [32][RES_HS]: output projection weights (resident for the launch)
+    static constexpr size_t x = z + (size_t)NP * RES_K2 * 2;              // fp32 [NP][RES_XS]
+    static constexpr size_t wo = x + (size_t)NP * RES_XS * 4;             // fp32 [32][RES_HS]: output projection weights (resident for the launch)
     static constexpr size_t par = wo + (size_t)RES_MAX_C * RES_HS * 4;    // fp32 [2][RES_PAR]: small parameters of the current / next stage
     static constexpr size_t rope = par + (size_t)2 * RES_PAR * 4;         // float2 [T + L][16]
     static constexpr size_t bytes(int T, int L) { return rope + (size_t)(T + L) * 16 * 8; }
 };
 
 __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// exact fp32 multiply-add (v_mfma_f32_16x16x4_f32): four k-steps from one float4 per operand.  Lane (r16, g4) supplies A[row r16][k] and
+// B[k][col r16] for the k values {4 g4 + e}; any k order is fine as long as both operands use the same one.
+__device__ __forceinline__ f32x4v mfma16_f32x4(float4 a, float4 b, f32x4v c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+}
 
 // sum over the 4 lanes {l, l^16, l^32, l^48} (the four 4-feature row groups of a 16x16 accumulator column): two VALU lane exchanges
 // (gfx950 v_permlane16_swap / v_permlane32_swap; with both operands = v the two results are the values of the even and of the odd
@@ -155,17 +190,26 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
     float *pars = reinterpret_cast<float *>(smem + LO::par);
     float2 *rope_l = reinterpret_cast<float2 *>(smem + LO::rope), *rope_t = rope_l + A.L * 16;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x, lane = tid & 63;  // (not const: RES_OPAQUE_LANE below)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, g4 = lane >> 4;
+    int r16 = lane & 15, g4 = lane >> 4;
+    // hipcc hoists every per-lane address of the phases below (dozens of 64-bit pairs) out of the step / block loops and then spills them;
+    // declaring the lane coordinates "modified" at the top of a loop body keeps each address computation next to its use
+#define RES_OPAQUE_LANE() asm volatile("" : "+v"(tid), "+v"(lane), "+v"(r16), "+v"(g4))
     const int b = blockIdx.x, n_t = A.n_t, C = A.C, T = A.T, L = A.L;
     const size_t xoff = (size_t)b * n_t * C;
     const float *cond = A.cond_emb + (size_t)b * n_t * D;
 
+#ifdef LSL_EXPERIMENTS
+    if (A.skip) {  // the phase-skipping probes read buffers nobody wrote: make them zeros, not whatever the previous kernel left in LDS
+        for (int i = threadIdx.x * 16; i < (int)LO::bytes(A.T, A.L); i += RES_NTHR * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0, 0, 0, 0};
+        __syncthreads();
+    }
+#endif
     // ---- once per launch: state, RoPE tables, zero padding rows of the MFMA token operands ---------------------------------------
-    for (int i = tid; i < n_t * RES_MAX_C; i += NT) {  // columns >= C are zero (the embedding walks all RES_MAX_C of them)
+    for (int i = tid; i < NP * RES_MAX_C; i += NT) {  // columns >= C and rows >= n_t are zero (the embedding's MFMA walks all of them)
         const int n = i / RES_MAX_C, c = i % RES_MAX_C;
-        xs[i] = c < C ? A.x[xoff + (size_t)n * C + c] : 0.0f;
+        xs[n * RES_XS + c] = (c < C && n < n_t) ? A.x[xoff + (size_t)n * C + c] : 0.0f;
     }
     for (int i = tid; i < (T + L) * 16; i += NT) {
         const int p = i < L * 16 ? i / 16 : (i - L * 16) / 16, j = i & 15;
@@ -175,29 +219,41 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
     }
     for (int i = tid; i < (NP - n_t) * (D * 2 / 16); i += NT) *reinterpret_cast<u32x4 *>(as + (size_t)n_t * 256 + i * 16) = u32x4{0, 0, 0, 0};
     for (int i = tid; i < (NP - n_t) * (RES_K2 * 2 / 16); i += NT) *reinterpret_cast<u32x4 *>(zs + (size_t)n_t * 768 + i * 16) = u32x4{0, 0, 0, 0};
-    const int e_d = tid & 127, e_par = tid >> 7;  // embedding: this thread's output column, token residue mod 4
-    // the conditioning embedding of this thread's (column, tokens) does not change between state updates: registers
-    float cnd[12];
+    // embedding (fp32 MFMA, features on accumulator rows): wave w owns features 16 w .. + 15 of all tokens.  Its slice of the input
+    // projection and of the conditioning embedding (the accumulators' initial value) is the same for every state update, but 20 registers
+    // are not free across the block loop: they are re-requested (L2 hits) in the head phase of the previous update
+    float4 wxf[2], cnd[NNT];
+    auto load_embed_operands = [&]() {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) cnd[k] = (e_par + 4 * k) < n_t ? cond[(size_t)(e_par + 4 * k) * D + e_d] : 0.0f;
+        for (int j = 0; j < 2; ++j) {
+            const int c = 16 * j + 4 * g4;
+            wxf[j] = *reinterpret_cast<const float4 *>(A.x_in_w + (size_t)(16 * wave + r16) * C + min(c, C - 4));
+            if (c >= C) wxf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) {
+            cnd[nt] = *reinterpret_cast<const float4 *>(cond + (size_t)min(16 * nt + r16, n_t - 1) * D + 16 * wave + 4 * g4);
+            if (16 * nt + r16 >= n_t) cnd[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_embed_operands();
     // parameter staging: stage q = s * (nb + 1) + bi (bi == nb: the output head); values travel global -> registers at the start of the
     // previous stage and registers -> LDS buffer (q & 1) at its end
     const int nb = 2 * A.depth;
     float pr[3];
     auto par_issue = [&](int s2, int bi2) {
         const float *mods2 = A.mods + (size_t)s2 * A.mods_step_stride + (size_t)b * A.mods_traj_stride;
-        // every lane loads unconditionally from a valid (clamped) address chosen by pointer arithmetic: a load inside a branch gets its
-        // s_waitcnt at the end of that branch, i.e. the "prefetch" would wait for L2 right here (measured: ~3 us per stage)
-        const ResBlock &B2 = A.blk[min(bi2, nb - 1)];
+        // every lane loads unconditionally from a valid (clamped) address: a load inside a branch gets its s_waitcnt at the end of that
+        // branch, i.e. the "prefetch" would wait for L2 right here (measured: ~3 us per stage)
+        const float *bp = A.blkpar + (size_t)min(bi2, nb - 1) * RES_P_SHIFT;
         const float *mb2 = mods2 + (size_t)(bi2 >> 1) * 6 * D + ((bi2 & 1) ? 3 * D : 0);  // (bi2 == nb: depth * 6 D = the adaLN rows)
         const bool head = bi2 >= nb;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int i = tid + NT * k;
-            const float *src = i < RES_P_QS ? B2.b1 + i : i < RES_P_KS ? B2.qs + (i - RES_P_QS) : i < RES_P_B2 ? B2.ks + (i - RES_P_KS)
-                               : i < RES_P_SHIFT ? B2.b2 + (i - RES_P_B2) : mb2 + min(i - RES_P_SHIFT, 3 * D - 1);
-            if (head) src = mb2 + min(i, 2 * D - 1);
-            pr[k] = *src;
+            const float *p0 = bp + min(i, RES_P_SHIFT - 1);
+            const float *p1 = mb2 + (head ? min(i, 2 * D - 1) : min(max(i - RES_P_SHIFT, 0), 3 * D - 1));
+            pr[k] = *((i < RES_P_SHIFT && !head) ? p0 : p1);
         }
     };
     auto par_commit = [&](int q) {
@@ -207,14 +263,16 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
     };
     par_issue(0, 0);
     par_commit(0);
-    // head: this thread's output channel and token group; the projection weights live in LDS (rows padded like h)
-    const int h_c = tid & 31, h_grp = tid >> 5;
+    // head (fp32 MFMA): the projection weights live in LDS (rows padded like h); wave w < 2 NNT owns channels 16 (w / NNT) .. + 15 of
+    // token tile w % NNT
     for (int i = tid; i < RES_MAX_C * (D / 4); i += NT) {
         const int c = i / (D / 4), d = (i % (D / 4)) * 4;
         *reinterpret_cast<float4 *>(wos + (size_t)c * RES_HS + d) =
             c < C ? *reinterpret_cast<const float4 *>(A.out_w + (size_t)c * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float bo = h_c < C ? A.out_b[h_c] : 0.0f;
+    const int h_nt = wave % NNT, h_ct = wave / NNT, h_c0 = 16 * h_ct + 4 * g4;
+    const bool h_on = wave < 2 * NNT && 16 * h_ct < C;  // (wave-uniform)
+    const float4 bo = (h_on && h_c0 < C) ? *reinterpret_cast<const float4 *>(A.out_b + h_c0) : make_float4(0.f, 0.f, 0.f, 0.f);
     res_barrier();
 
     // positions of this lane's NNT tokens along the two attended axes (no integer division in the epilogues)
@@ -225,80 +283,99 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
         pos_l[nt] = nn % L;
         pos_t[nt] = nn / L;
     }
-    // LayerNorm (+ optional modulate) of the rows of h, 16 lanes per row (8 values each), 4 rows per wave pass.
+    // LayerNorm (+ optional modulate) of the rows of h: 8 lanes per row (16 values each), 8 rows per wave, every row in ONE pass (64 >= NP).
     // MODE 0: h <- LN_eps(h) in place; MODE 1: a (bf16, swizzled) <- LN(h)(1+scale)+shift; MODE 2: fp32 rows into `dst` (stride RES_HS)
+    auto row8_sum = [&](float v) {  // sum over a group of 8 consecutive lanes: quad xor 1, quad xor 2, row_half_mirror
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+        return v;
+    };
     auto layer_norm = [&](int mode, float eps, const float *shift, const float *scale, float *dst) {
-        const int sub = lane >> 4, col = (lane & 15) * 8;
-        for (int row = wave * 4 + sub; row < ((n_t + 15) & ~15); row += 4 * RES_NW) {
-            const bool ok = row < n_t;
-            const float *hp = hs + (size_t)(ok ? row : 0) * RES_HS + col;
-            const float4 v0 = *reinterpret_cast<const float4 *>(hp), v1 = *reinterpret_cast<const float4 *>(hp + 4);
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            const float mean = row16_sum(s) * (1.0f / D);
-            float q = 0.0f;
+        const int row = wave * 8 + (lane >> 3), l8 = lane & 7, col = l8 * 16;
+        if (wave * 8 >= n_t) return;  // (wave-uniform)
+        const bool ok = row < n_t;
+        const float *hp = hs + (size_t)(ok ? row : 0) * RES_HS + col;
+        float v[16];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[e] -= mean;
-                q = fmaf(v[e], v[e], q);
-            }
-            const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + eps);
-            if (mode != 0) {
-                const float4 s0 = *reinterpret_cast<const float4 *>(scale + col), s1 = *reinterpret_cast<const float4 *>(scale + col + 4);
-                const float4 f0 = *reinterpret_cast<const float4 *>(shift + col), f1 = *reinterpret_cast<const float4 *>(shift + col + 4);
-                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sf[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 t = *reinterpret_cast<const float4 *>(hp + 4 * c4);
+            v[4 * c4] = t.x; v[4 * c4 + 1] = t.y; v[4 * c4 + 2] = t.z; v[4 * c4 + 3] = t.w;
+        }
+        float s = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e] * rstd, 1.0f + sc[e], sf[e]);
-            } else {
+        for (int c4 = 0; c4 < 4; ++c4) s += (v[4 * c4] + v[4 * c4 + 1]) + (v[4 * c4 + 2] + v[4 * c4 + 3]);
+        const float mean = row8_sum(s) * (1.0f / D);
+        float q = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= rstd;
+        for (int e = 0; e < 16; ++e) {
+            v[e] -= mean;
+            q = fmaf(v[e], v[e], q);
+        }
+        const float rstd = rsqrtf(row8_sum(q) * (1.0f / D) + eps);
+        if (mode != 0) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float4 sc = *reinterpret_cast<const float4 *>(scale + col + 4 * c4), sf = *reinterpret_cast<const float4 *>(shift + col + 4 * c4);
+                v[4 * c4] = fmaf(v[4 * c4] * rstd, 1.0f + sc.x, sf.x);
+                v[4 * c4 + 1] = fmaf(v[4 * c4 + 1] * rstd, 1.0f + sc.y, sf.y);
+                v[4 * c4 + 2] = fmaf(v[4 * c4 + 2] * rstd, 1.0f + sc.z, sf.z);
+                v[4 * c4 + 3] = fmaf(v[4 * c4 + 3] * rstd, 1.0f + sc.w, sf.w);
             }
-            if (!ok) continue;
-            if (mode == 1) {
-                const u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                *reinterpret_cast<u32x4 *>(as + (size_t)row * 256 + res_swz(row, lane & 15)) = pk;
-            } else {
-                float *o = (mode == 0 ? hs : dst) + (size_t)row * RES_HS + col;
-                *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] *= rstd;
+        }
+        if (!ok) return;
+        if (mode == 1) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const u32x4 pk = {pack2(v[8 * h2], v[8 * h2 + 1]), pack2(v[8 * h2 + 2], v[8 * h2 + 3]), pack2(v[8 * h2 + 4], v[8 * h2 + 5]), pack2(v[8 * h2 + 6], v[8 * h2 + 7])};
+                *reinterpret_cast<u32x4 *>(as + (size_t)row * 256 + res_swz(row, 2 * l8 + h2)) = pk;
             }
+        } else {
+            float *o = (mode == 0 ? hs : dst) + (size_t)row * RES_HS + col;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<float4 *>(o + 4 * c4) = make_float4(v[4 * c4], v[4 * c4 + 1], v[4 * c4 + 2], v[4 * c4 + 3]);
         }
     };
 
-    // W fragments of one 16-feature tile: lane (r16, g4) holds W[f0 + r16][32 ks + 8 g4 .. + 7] for every k-step (row-contiguous weights:
-    // the four 1 KiB loads of a K = 128 tile cover one contiguous 4 KiB block)
+    // W fragments of one 16-feature tile (rows f0 .. f0 + 15, f0 a multiple of 16): lane (r16, g4) gets W[f0 + r16][32 ks + 8 g4 .. + 7] for
+    // every k-step; in the packed order that is 16 bytes at (tile, ks, lane): every load instruction reads 1 KiB contiguous
     auto load_w = [&](const u16 *W, int K, int f0, int nks, bf16x8 *dst) {
-        const u16 *p = W + (size_t)(f0 + r16) * K + 8 * g4;
+        const u16 *p = W + (size_t)f0 * K + 8 * lane;
 #pragma unroll 12
-        for (int ks = 0; ks < nks; ++ks) dst[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(p + 32 * ks));
+        for (int ks = 0; ks < nks; ++ks) dst[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(p + 512 * ks));
     };
 
+    // linear1's 40 feature tiles of 16, five per wave with the same mix in every wave (equal MFMA and VALU work, no loop, no branch):
+    // one q (waves 0-3) or k (waves 4-7) head = 2 tiles, one v tile, two mlp tiles (one GELU pair)
+    const int l1_sec = wave >> 2;
+    const int l1_f[5] = {l1_sec * RES_HHD + (wave & 3) * RES_HD, l1_sec * RES_HHD + (wave & 3) * RES_HD + 16, 2 * RES_HHD + 16 * wave,
+                         3 * RES_HHD + 32 * wave, 3 * RES_HHD + 32 * wave + 16};
+    bf16x8 w1f[5][4];  // their weight fragments, requested one phase ahead of their use
+    auto load_w1 = [&](const u16 *W1) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) load_w(W1, D, l1_f[t], 4, w1f[t]);
+    };
+    load_w1(A.blk[0].w1);
 #ifdef LSL_EXPERIMENTS
     unsigned long long stamp_t_ = __builtin_amdgcn_s_memtime();
 #endif
     for (int s = 0; s < A.n_steps; ++s) {
+        RES_OPAQUE_LANE();
         // ---- embedding: h = x Wx^T + cond_emb (latent_si_v31.py:172), optional LayerNorm eps 1e-5 (:173-174) -------------------
-        float wx[RES_MAX_C];  // this thread's column of the input projection (L1-resident; live only here: 256-VGPR budget)
+        // features 16 w .. + 15 (accumulator rows 4 g4 .. + 3) of every token (lanes r16), k = the C <= 32 input channels, fp32 MFMA
 #pragma unroll
-        for (int c = 0; c < RES_MAX_C; c += 4) {
-            const float4 w4 = c < C ? *reinterpret_cast<const float4 *>(A.x_in_w + (size_t)e_d * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            wx[c] = w4.x; wx[c + 1] = w4.y; wx[c + 2] = w4.z; wx[c + 3] = w4.w;
-        }
+        for (int nt = 0; nt < NNT; ++nt) {
+            f32x4v acc = {cnd[nt].x, cnd[nt].y, cnd[nt].z, cnd[nt].w};
+            const float *xr = xs + (16 * nt + r16) * RES_XS + 4 * g4;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const int n = e_par + 4 * k;
-            if (n >= n_t) continue;  // (a full unroll with static register indices: cnd[] must not be indexed dynamically)
-            float acc = cnd[k];
-            const float *xr = xs + n * RES_MAX_C;
-#pragma unroll
-            for (int c = 0; c < RES_MAX_C; c += 4) {
-                const float4 xv = *reinterpret_cast<const float4 *>(xr + c);
-                acc = fmaf(xv.x, wx[c], acc);
-                acc = fmaf(xv.y, wx[c + 1], acc);
-                acc = fmaf(xv.z, wx[c + 2], acc);
-                acc = fmaf(xv.w, wx[c + 3], acc);
+            for (int j = 0; j < 2; ++j) {
+                if (16 * j >= C) break;  // (uniform)
+                acc = mfma16_f32x4(wxf[j], *reinterpret_cast<const float4 *>(xr + 16 * j), acc);
             }
-            hs[(size_t)n * RES_HS + e_d] = acc;
+            if (16 * nt + r16 < n_t) *reinterpret_cast<float4 *>(hs + (size_t)(16 * nt + r16) * RES_HS + 16 * wave + 4 * g4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
         res_barrier();
         if (A.normalize) {
@@ -308,104 +385,118 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
         RES_STAMP(4);
 
         for (int bi = 0; bi < nb; ++bi) {
+            RES_OPAQUE_LANE();
             const ResBlock &B = A.blk[bi];
             const int temporal = bi & 1;
             const int q = s * (nb + 1) + bi;
             const float *pb = pars + (q & 1) * RES_PAR;  // this stage's small parameters (LDS)
             par_issue(s, bi + 1);                        // the next stage's (bi + 1 == nb: the head) travel to registers meanwhile
-            // first weight fragments of linear1 are requested before the LayerNorm: they do not depend on it
-            bf16x8 wA[2][4];
-            load_w(B.w1, D, wave * 32, 4, wA[0]);
-            load_w(B.w1, D, wave * 32 + 16, 4, wA[1]);
             if (!LSL_PROBE(A.skip, 8)) layer_norm(1, 1e-6f, pb + RES_P_SHIFT, pb + RES_P_SCALE, nullptr);
             res_barrier();
             RES_STAMP(0);
             // ---- linear1 (+ bias, QK-RMSNorm, RoPE, GELU): a[NP][128] x W1[640][128]^T -> qkv, z ---------------------------------
-            // 20 pairs of 16-feature tiles (one 32-wide head, or 32 mlp features), pairs wave, wave + 8, wave + 16
-            if (!LSL_PROBE(A.skip, 2)) {
+            // Straight-line code, the same five tiles for every wave (l1_f): the weights were requested a phase ago (w1f), the token
+            // operand is read once, all 60 MFMAs are issued back to back - the mlp tiles first, so that their GELUs (the longest VALU
+            // chains) run in the shadow of the other tiles' MFMAs - and linear2's weight tile is requested as soon as w1f is dead.
+            bf16x8 w2f[12];
+            {
                 bf16x8 xf[NNT][4];
 #pragma unroll
                 for (int nt = 0; nt < NNT; ++nt)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
                         xf[nt][ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(as + (size_t)(16 * nt + r16) * 256 + res_swz(16 * nt + r16, 4 * ks + g4)));
-                const float2 *rtab = temporal ? rope_t : rope_l;
-                // One weight buffer, refilled for the NEXT pair right after the current pair's MFMAs have been issued: the loads then have the
-                // whole epilogue to land, and at the top of the loop the only vector-memory operations in flight are exactly the fragments
-                // the MFMAs need.  (With a second buffer prefetched BEFORE the MFMAs, hipcc's s_waitcnt bookkeeping merges the loop paths
-                // and waits vmcnt(0) in front of the first MFMA, i.e. for the prefetch itself - seen in the .s as vmcnt(7) ... vmcnt(0).)
-#pragma unroll 1
-                for (int pair = wave; pair < 20; pair += RES_NW) {
-                    const int f0 = pair * 32;
-                    f32x4v acc[2][NNT];
+                f32x4v acc[5][NNT];
 #pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const float4 bq = *reinterpret_cast<const float4 *>(pb + f0 + 16 * ii + 4 * g4);
+                for (int t = 0; t < 5; ++t) {
+                    const float4 bq = *reinterpret_cast<const float4 *>(pb + l1_f[t] + 4 * g4);
 #pragma unroll
-                        for (int nt = 0; nt < NNT; ++nt) acc[ii][nt] = f32x4v{bq.x, bq.y, bq.z, bq.w};
-                    }
+                    for (int nt = 0; nt < NNT; ++nt) acc[t][nt] = f32x4v{bq.x, bq.y, bq.z, bq.w};
+                }
+                // tile-major; once the NEXT tile's MFMAs are issued a tile's weight registers are refilled with the next stage's tile (the
+                // next block's, or block 0's for the next state update): the weight stream (the CU takes ~24 cycles per 1 KiB load, 256
+                // loads per sub-block) then runs under this phase's MFMAs and VALU-heavy epilogue instead of in front of linear2
+                const u16 *w1n = A.blk[bi + 1 < nb ? bi + 1 : 0].w1;
+                // (One tile behind, and the scheduler may not move anything across the fences.  With the loads issued directly behind their
+                // own tile's MFMAs the two-tile instance of this kernel produced run-to-run differences of 1e-7 .. 1e-5 - see
+                // profiles/r02_resident.txt; cause not established, every variant that keeps a tile of MFMAs or a VALU block between
+                // an MFMA and the next load into a register it read is bit-stable over thousands of reruns.)
+#pragma unroll
+                for (int tt = 0; tt < 5; ++tt) {
+                    const int t = (tt + 3) % 5;  // 3, 4 (mlp), 0, 1 (head), 2 (v)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                        for (int ii = 0; ii < 2; ++ii)
+                        for (int nt = 0; nt < NNT; ++nt) acc[t][nt] = mfma16(w1f[t][ks], xf[nt][ks], acc[t][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tt >= 1) load_w(w1n, D, l1_f[(tt + 2) % 5], 4, w1f[(tt + 2) % 5]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float2 *rtab = temporal ? rope_t : rope_l;
+                // mlp: erf-GELU, z columns HHD + (f - 3 HHD)
 #pragma unroll
-                            for (int nt = 0; nt < NNT; ++nt) acc[ii][nt] = mfma16(wA[ii][ks], xf[nt][ks], acc[ii][nt]);
-                    if (pair + RES_NW < 20) {
-                        load_w(B.w1, D, f0 + RES_NW * 32, 4, wA[0]);
-                        load_w(B.w1, D, f0 + RES_NW * 32 + 16, 4, wA[1]);
-                    }
-                    const int sec = pair >> 2;  // 0 q, 1 k, 2 v, 3-4 mlp (wave-uniform)
+                for (int nt = 0; nt < NNT; ++nt) {
+                    const int n = 16 * nt + r16;
 #pragma unroll
-                    for (int nt = 0; nt < NNT; ++nt) {
-                        const int n = 16 * nt + r16;
-                        float v[8] = {acc[0][nt][0], acc[0][nt][1], acc[0][nt][2], acc[0][nt][3], acc[1][nt][0], acc[1][nt][1], acc[1][nt][2], acc[1][nt][3]};
-                        if (sec < 2) {
-                            float ss = 0.0f;
+                    for (int ii = 0; ii < 2; ++ii) {
+                        float v[4];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
-                            ss = col_sum4(ss);
-                            const float rr = rsqrtf(fmaf(ss, 1.0f / RES_HD, 1e-6f)) * (sec == 0 ? A.q_premul : 1.0f);
-                            const int pos = temporal ? pos_t[nt] : pos_l[nt];
-                            const float *sc = pb + (sec == 0 ? RES_P_QS : RES_P_KS);
-#pragma unroll
-                            for (int ii = 0; ii < 2; ++ii) {
-                                const int d0 = 16 * ii + 4 * g4;  // first of this lane's 4 consecutive channels inside the head
-                                const float4 s4 = *reinterpret_cast<const float4 *>(sc + d0);
-                                const float4 cs = *reinterpret_cast<const float4 *>(rtab + pos * 16 + (d0 >> 1));  // (c0, s0, c1, s1)
-                                const float x0 = v[4 * ii] * rr * s4.x, x1 = v[4 * ii + 1] * rr * s4.y, x2 = v[4 * ii + 2] * rr * s4.z, x3 = v[4 * ii + 3] * rr * s4.w;
-                                v[4 * ii] = cs.x * x0 - cs.y * x1;
-                                v[4 * ii + 1] = cs.y * x0 + cs.x * x1;
-                                v[4 * ii + 2] = cs.z * x2 - cs.w * x3;
-                                v[4 * ii + 3] = cs.w * x2 + cs.z * x3;
-                            }
-                        } else if (sec >= 3) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(acc[3 + ii][nt][e]);
                         if (n < n_t) {
-#pragma unroll
-                            for (int ii = 0; ii < 2; ++ii) {
-                                const u32x2 pk = {pack2(v[4 * ii], v[4 * ii + 1]), pack2(v[4 * ii + 2], v[4 * ii + 3])};
-                                const int f = f0 + 16 * ii + 4 * g4;
-                                if (sec < 3) *reinterpret_cast<u32x2 *>(qs_ + (size_t)n * RES_QS + f) = pk;
-                                else {  // z column = HHD + (f - 3 HHD): 16-byte chunk index, 8-byte half inside it
-                                    const int zc = f - 2 * RES_HHD;
-                                    *reinterpret_cast<u32x2 *>(zs + (size_t)n * 768 + res_swz(n, zc >> 3) + (zc & 4) * 2) = pk;
-                                }
-                            }
+                            const u32x2 pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                            const int zc = l1_f[3 + ii] + 4 * g4 - 2 * RES_HHD;  // 16-byte chunk index zc >> 3, 8-byte half inside it
+                            *reinterpret_cast<u32x2 *>(zs + (size_t)n * 768 + res_swz(n, zc >> 3) + (zc & 4) * 2) = pk;
                         }
                     }
                 }
+                // the last tile's refill and linear2's weight tile: behind the GELU block
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(w1n, D, l1_f[2], 4, w1f[2]);
+                load_w(B.w2, RES_K2, wave * 16, 12, w2f);
+                __builtin_amdgcn_sched_barrier(0);
+                // this wave's q (waves 0-3) or k (4-7) head: RMS norm over the head's 32 channels, scale, RoPE (q: * softmax scale * log2 e)
+                const float *sc = pb + (l1_sec == 0 ? RES_P_QS : RES_P_KS);
+                const float post = l1_sec == 0 ? A.q_premul : 1.0f;
+#pragma unroll
+                for (int nt = 0; nt < NNT; ++nt) {
+                    const int n = 16 * nt + r16;
+                    float v[8] = {acc[0][nt][0], acc[0][nt][1], acc[0][nt][2], acc[0][nt][3], acc[1][nt][0], acc[1][nt][1], acc[1][nt][2], acc[1][nt][3]};
+                    {
+                        float ss = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
+                        ss = col_sum4(ss);
+                        const float rr = rsqrtf(fmaf(ss, 1.0f / RES_HD, 1e-6f)) * post;
+                        const int pos = temporal ? pos_t[nt] : pos_l[nt];
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            const int d0 = 16 * ii + 4 * g4;  // first of this lane's 4 consecutive channels inside the head
+                            const float4 s4 = *reinterpret_cast<const float4 *>(sc + d0);
+                            const float4 cs = *reinterpret_cast<const float4 *>(rtab + pos * 16 + (d0 >> 1));  // (c0, s0, c1, s1)
+                            const float x0 = v[4 * ii] * rr * s4.x, x1 = v[4 * ii + 1] * rr * s4.y, x2 = v[4 * ii + 2] * rr * s4.z, x3 = v[4 * ii + 3] * rr * s4.w;
+                            v[4 * ii] = cs.x * x0 - cs.y * x1;
+                            v[4 * ii + 1] = cs.y * x0 + cs.x * x1;
+                            v[4 * ii + 2] = cs.z * x2 - cs.w * x3;
+                            v[4 * ii + 3] = cs.w * x2 + cs.z * x3;
+                        }
+                    }
+                    if (n < n_t) {
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            const u32x2 pk = {pack2(v[4 * ii], v[4 * ii + 1]), pack2(v[4 * ii + 2], v[4 * ii + 3])};
+                            *reinterpret_cast<u32x2 *>(qs_ + (size_t)n * RES_QS + l1_f[ii] + 4 * g4) = pk;
+                        }
+                        const u32x2 pv = {pack2(acc[2][nt][0], acc[2][nt][1]), pack2(acc[2][nt][2], acc[2][nt][3])};  // v: as is
+                        *reinterpret_cast<u32x2 *>(qs_ + (size_t)n * RES_QS + l1_f[2] + 4 * g4) = pv;
+                    }
+                }
             }
-            // linear2's weight tile (one 16-feature tile per wave) is requested before the attention
-            bf16x8 w2f[12];
-            load_w(B.w2, RES_K2, wave * 16, 12, w2f);
             res_barrier();
             RES_STAMP(1);
             // ---- attention over the spatial (sequence (t), positions l) or temporal (sequence (l), positions t) axis ------------------
             const int S = temporal ? T : L, n_seq = temporal ? L : T, sstride = temporal ? L : 1, qbase_mul = temporal ? 1 : L;
             if (LSL_PROBE(A.skip, 1)) {
-            } else if (S > 8 && S <= 32) {
+            } else if (S > 8) {  // (S <= 32: resident_ok)
                 // MFMA form, one unit = (sequence, head, 16-query tile): St = K Q^T (keys on accumulator rows, queries on lanes), softmax over
                 // this lane's 4 (x2 key tiles) scores and the three other row groups of the column, Ot = V^T P^T with P taken straight from
                 // the accumulator registers as the B operand (k slot j of row group g: key 4g + j for j < 4, key 16 + 4g + j - 4 otherwise) and
@@ -459,59 +550,58 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
                     }
                 }
             } else {
-                // short (or long) sequences: one lane per (query token, head); keys walk the sequence with an online softmax (fp32 probabilities)
+                // short sequences (S <= 8): one lane per (query token, head), fp32 probabilities.  The head's 32 channels are walked in four
+                // 8-channel chunks (scores first, then the weighted sum chunk by chunk): ~40 live registers instead of q[32] + o[32], which
+                // this phase does not have beside the 128 weight registers that are in flight for linear2 and the next linear1
                 for (int item = tid; item < n_t * RES_H; item += NT) {
                     const int n = item >> 2, hh = item & 3;
                     const int k0 = temporal ? n % L : (n / L) * L;
-                    float q[RES_HD];
-                    {
-                        const u16 *qp = qs_ + (size_t)n * RES_QS + hh * RES_HD;
+                    const u16 *qp = qs_ + (size_t)n * RES_QS + hh * RES_HD;
+                    const u16 *kp = qs_ + (size_t)k0 * RES_QS + RES_HHD + hh * RES_HD;  // key j: kp + j * sstride * RES_QS; value: + RES_HHD
+                    float dot[8];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const u32x4 w = *reinterpret_cast<const u32x4 *>(qp + 8 * c);
+                    for (int j = 0; j < 8; ++j) dot[j] = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const u32x4 qw = *reinterpret_cast<const u32x4 *>(qp + 8 * c);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (j >= S) break;  // (uniform)
+                            const u32x4 w = *reinterpret_cast<const u32x4 *>(kp + (size_t)j * sstride * RES_QS + 8 * c);
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                q[8 * c + 2 * k] = __uint_as_float(w[k] << 16);
-                                q[8 * c + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+                                dot[j] = fmaf(__uint_as_float(qw[k] << 16), __uint_as_float(w[k] << 16), dot[j]);
+                                dot[j] = fmaf(__uint_as_float(qw[k] & 0xffff0000u), __uint_as_float(w[k] & 0xffff0000u), dot[j]);
                             }
                         }
                     }
-                    float o[RES_HD];
+                    float mx = dot[0];
 #pragma unroll
-                    for (int d = 0; d < RES_HD; ++d) o[d] = 0.0f;
-                    float mx = -INFINITY, sum = 0.0f;
-                    for (int j = 0; j < S; ++j) {
-                        const u16 *kp = qs_ + (size_t)(k0 + j * sstride) * RES_QS + RES_HHD + hh * RES_HD;
-                        float dot = 0.0f;
+                    for (int j = 1; j < 8; ++j)
+                        if (j < S) mx = fmaxf(mx, dot[j]);
+                    float sum = 0.0f;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const u32x4 w = *reinterpret_cast<const u32x4 *>(kp + 8 * c);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                dot = fmaf(q[8 * c + 2 * k], __uint_as_float(w[k] << 16), dot);
-                                dot = fmaf(q[8 * c + 2 * k + 1], __uint_as_float(w[k] & 0xffff0000u), dot);
-                            }
-                        }
-                        const float mnew = fmaxf(mx, dot);
-                        const float alpha = __builtin_amdgcn_exp2f(mx - mnew), p = __builtin_amdgcn_exp2f(dot - mnew);
-                        mx = mnew;
-                        sum = fmaf(sum, alpha, p);
-                        const u16 *vp = kp + RES_HHD;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const u32x4 w = *reinterpret_cast<const u32x4 *>(vp + 8 * c);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                o[8 * c + 2 * k] = fmaf(o[8 * c + 2 * k], alpha, p * __uint_as_float(w[k] << 16));
-                                o[8 * c + 2 * k + 1] = fmaf(o[8 * c + 2 * k + 1], alpha, p * __uint_as_float(w[k] & 0xffff0000u));
-                            }
-                        }
+                    for (int j = 0; j < 8; ++j) {
+                        dot[j] = j < S ? __builtin_amdgcn_exp2f(dot[j] - mx) : 0.0f;
+                        sum += dot[j];
                     }
                     const float inv = 1.0f / sum;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const u32x4 w = {pack2(o[8 * c] * inv, o[8 * c + 1] * inv), pack2(o[8 * c + 2] * inv, o[8 * c + 3] * inv),
-                                         pack2(o[8 * c + 4] * inv, o[8 * c + 5] * inv), pack2(o[8 * c + 6] * inv, o[8 * c + 7] * inv)};
+                        float o[8];
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) o[d] = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (j >= S) break;
+                            const u32x4 w = *reinterpret_cast<const u32x4 *>(kp + (size_t)j * sstride * RES_QS + RES_HHD + 8 * c);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                o[2 * k] = fmaf(dot[j], __uint_as_float(w[k] << 16), o[2 * k]);
+                                o[2 * k + 1] = fmaf(dot[j], __uint_as_float(w[k] & 0xffff0000u), o[2 * k + 1]);
+                            }
+                        }
+                        const u32x4 w = {pack2(o[0] * inv, o[1] * inv), pack2(o[2] * inv, o[3] * inv), pack2(o[4] * inv, o[5] * inv), pack2(o[6] * inv, o[7] * inv)};
                         *reinterpret_cast<u32x4 *>(zs + (size_t)n * 768 + res_swz(n, 4 * hh + c)) = w;
                     }
                 }
@@ -557,34 +647,40 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
         const int qh = s * (nb + 1) + nb;
         const float *ph = pars + (qh & 1) * RES_PAR;  // adaLN: shift [0, D), scale [D, 2 D)
         if (s + 1 < A.n_steps) par_issue(s + 1, 0);
+        load_embed_operands();  // for the next update's embedding
         float *ln = reinterpret_cast<float *>(smem + LO::qkv);  // fp32 rows [n_t][RES_HS]: q/k/v are dead here (NP * 784 B >= n_t * 528 B)
         layer_norm(2, 1e-6f, ph, ph + D, ln);
         res_barrier();
         const float4 sp = A.step[s];  // (t, ax, am, aw)
-        if (h_c < C) {
-            for (int n = h_grp; n < n_t; n += NT / 32) {
-                const float *lr = ln + (size_t)n * RES_HS, *wr = wos + (size_t)h_c * RES_HS;
-                float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-#pragma unroll 8
-                for (int d = 0; d < D; d += 4) {
-                    const float4 lv = *reinterpret_cast<const float4 *>(lr + d), wv = *reinterpret_cast<const float4 *>(wr + d);
-                    acc0 = fmaf(lv.x, wv.x, acc0);
-                    acc1 = fmaf(lv.y, wv.y, acc1);
-                    acc2 = fmaf(lv.z, wv.z, acc2);
-                    acc3 = fmaf(lv.w, wv.w, acc3);
+        if (h_on) {
+            // out[c][n] = sum_d Wo[c][d] ln[n][d]: channels on accumulator rows, tokens on lanes, exact fp32 MFMA (both operands from LDS,
+            // 16 bytes per lane and read; rows >= n_t of `ln` are stale q/k/v bytes: they only reach token columns that are not stored)
+            const float *wr = wos + (size_t)(16 * h_ct + r16) * RES_HS + 4 * g4, *lr = ln + (size_t)(16 * h_nt + r16) * RES_HS + 4 * g4;
+            f32x4v acc = {bo.x, bo.y, bo.z, bo.w};
+#pragma unroll
+            for (int j = 0; j < D / 16; ++j)
+                acc = mfma16_f32x4(*reinterpret_cast<const float4 *>(wr + 16 * j), *reinterpret_cast<const float4 *>(lr + 16 * j), acc);
+            const int n = 16 * h_nt + r16;
+            if (n < n_t && h_c0 < C) {
+                const size_t e = xoff + (size_t)n * C + h_c0;
+                float *xp = xs + n * RES_XS + h_c0;
+                const float4 xo = *reinterpret_cast<const float4 *>(xp);
+                float xn[4] = {sp.y * xo.x + sp.z * acc[0], sp.y * xo.y + sp.z * acc[1], sp.y * xo.z + sp.z * acc[2], sp.y * xo.w + sp.z * acc[3]};
+                if (sp.w != 0.0f) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        xn[k] += sp.w * (A.noise ? A.noise[(size_t)(A.step0 + s) * A.noise_step_stride + e + k] : philox_normal(A.seed, A.step0 + s, A.elem_offset + e + k));
                 }
-                const float mo = ((acc0 + acc1) + (acc2 + acc3)) + bo;
-                const size_t e = xoff + (size_t)n * C + h_c;
-                float xn = sp.y * xs[n * RES_MAX_C + h_c] + sp.z * mo;
-                if (sp.w != 0.0f)
-                    xn += sp.w * (A.noise ? A.noise[(size_t)(A.step0 + s) * A.noise_step_stride + e] : philox_normal(A.seed, A.step0 + s, A.elem_offset + e));
-                xs[n * RES_MAX_C + h_c] = xn;
-                if (A.trace) A.trace[(size_t)(A.step0 + s) * A.trace_step_stride + e] = xn;
+                *reinterpret_cast<float4 *>(xp) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+                if (A.trace) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) A.trace[(size_t)(A.step0 + s) * A.trace_step_stride + e + k] = xn[k];
+                }
             }
         }
         if (s + 1 < A.n_steps) par_commit(qh + 1);
         res_barrier();
         RES_STAMP(5);
     }
-    for (int i = tid; i < n_t * C; i += NT) A.x[xoff + i] = xs[(i / C) * RES_MAX_C + (i % C)];
+    for (int i = tid; i < n_t * C; i += NT) A.x[xoff + i] = xs[(i / C) * RES_XS + (i % C)];
 }

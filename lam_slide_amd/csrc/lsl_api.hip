@@ -663,11 +663,12 @@ bool resident_ok(const lsl_model *m, int T, int L) {
     static const int off = env_int("LSL_RESIDENT", 1) == 0;  // documented runtime switch: 0 = always the general path
     const lsl_model_desc &d = m->d;
     return !off && d.hidden == RES_D && d.heads == RES_H && d.head_dim == RES_HD && d.head_dim_pad == RES_HD && d.mlp_dim == RES_M &&
-           d.in_dim <= RES_MAX_C && d.in_dim % 4 == 0 && 2 * d.depth <= RES_MAX_BLOCKS && (long)T * L <= 48 && T + L <= 64;
+           d.in_dim <= RES_MAX_C && d.in_dim % 4 == 0 && 2 * d.depth <= RES_MAX_BLOCKS && (long)T * L <= 48 && T <= 32 && L <= 32;
 }
 
 struct ResWorkspace {
-    float *cond_emb, *yemb, *tfeat, *hid, *vec, *mods;
+    float *cond_emb, *yemb, *tfeat, *hid, *vec, *mods, *blkpar;
+    u16 *blkw;
     int steps_per_launch;
     size_t bytes;
 };
@@ -691,6 +692,8 @@ ResWorkspace carve_resident(const lsl_model *m, char *base, int B, int T, int L,
     ws.hid = (float *)take(std::max(rt, (size_t)B) * D * 4);
     ws.vec = (float *)take(rt * D * 4);
     ws.mods = (float *)take(rt * m->MODW * 4);
+    ws.blkpar = (float *)take((size_t)2 * m->d.depth * RES_P_SHIFT * 4);
+    ws.blkw = (u16 *)take((size_t)2 * m->d.depth * (RES_W1_ELEMS + RES_W2_ELEMS) * 2);
     ws.bytes = off;
     return ws;
 }
@@ -737,10 +740,17 @@ int resident_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int n
     a.theta = d.theta;
     a.skip = tune_int("LSL_RES_SKIP", 0);
     a.q_premul = (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
+    ResPack pack;
     for (int bi = 0; bi < 2 * d.depth; ++bi) {
         const lsl_block_weights &bw = m->blocks[bi];
-        a.blk[bi] = ResBlock{(const u16 *)bw.w1, bw.b1, bw.qs, bw.ks, (const u16 *)bw.w2, bw.b2};
+        const u16 *wb = ws.blkw + (size_t)bi * (RES_W1_ELEMS + RES_W2_ELEMS);
+        a.blk[bi] = ResBlock{wb, wb + RES_W1_ELEMS};
+        pack.w1[bi] = (const u16 *)bw.w1; pack.w2[bi] = (const u16 *)bw.w2;
+        pack.b1[bi] = bw.b1; pack.qs[bi] = bw.qs; pack.ks[bi] = bw.ks; pack.b2[bi] = bw.b2;
     }
+    hipLaunchKernelGGL(k_res_pack, dim3(2 * d.depth, 49), dim3(256), 0, st, ws.blkw, ws.blkpar, pack);
+    LSL_CHECK_LAUNCH("k_res_pack");
+    a.blkpar = ws.blkpar;
     for (int s0 = 0; s0 < n_steps; s0 += ws.steps_per_launch) {
         const int ns = std::min(ws.steps_per_launch, n_steps - s0);
         StepTimes tt;

@@ -329,3 +329,29 @@ def test_resident_kernel_many_updates_and_device_noise(dev):
 
     full = run(0, 3)
     assert torch.equal(full, torch.cat([run(0, 1), run(1, 3)])) and torch.isfinite(full).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(10, 2, 32, False, 2), (8, 4, 32, False, 2), (5, 6, 32, False, 2), (3, 1, 8, True, 1), (17, 1, 32, False, 1),
+                                   (20, 2, 32, True, 6), (12, 4, 16, False, 2)])
+def test_resident_kernel_rerun_bits(shape, dev):
+    """The same call, repeated: every run gives the same bits.  Regression test for two defects found in round 2 while the resident
+    kernel was rebuilt around its weight stream: an inline-asm v_max_f32 that read an MFMA result with no wait states (wrong results,
+    timing-dependent), and run-to-run differences of 1e-7..1e-5 in the two-tile instance when weight loads were issued directly behind
+    the MFMAs of the tile they refill (profiles/r02_resident.txt).  8 state updates x 30 reruns per shape; both tile counts covered."""
+    from lam_slide_amd import CreateTransport, Sampler
+    from oracle import harness
+    T, L, C, norm, depth = shape
+    kw = dict(depth=depth, in_dim=C, hidden_size=128, num_heads=4, mlp_ratio=2, normalize=norm)
+    net, sh, p = _net(kw, 31, dev)
+    B = 5
+    g = torch.Generator().manual_seed(5)
+    lat, init = torch.randn(B, T, L, C, generator=g), torch.randn(B, T, L, C, generator=g)
+    xc, m = harness.setup_conditioning(lat, (0, min(3, T - 1)), True)
+    mk = {"x_cond": xc.to(dev), "x_cond_mask": m.to(dev)}
+    s = Sampler(CreateTransport("GVP", "data")(), fused=True)
+    fn = s.get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": 9})
+    ref = fn(init.to(dev), net.forward, **mk)[-1]
+    assert s.last_kernels == "resident" and torch.isfinite(ref).all()
+    differ = sum(0 if torch.equal(fn(init.to(dev), net.forward, **mk)[-1], ref) else 1 for _ in range(30))
+    assert differ == 0, f"{differ}/30 reruns differ"

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lam_slide_amd import _lib  # noqa: E402
 
-exp = os.path.join(ROOT, "tools", "_exp", "liblamslide_hip_exp.so")
+exp = os.path.join(ROOT, os.environ["LSL_LIB"]) if os.environ.get("LSL_LIB") else os.path.join(ROOT, "tools", "_exp", "liblamslide_hip_exp.so")
 if not os.path.exists(exp):
     raise SystemExit("run tools/build_experiments.sh first")
 _lib.LIB_PATH = exp

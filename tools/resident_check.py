@@ -1,5 +1,7 @@
 import sys, time, os, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+from lam_slide_amd import _lib
+if os.environ.get('LSL_LIB'): _lib.LIB_PATH = os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), os.environ['LSL_LIB'])
 from lam_slide_amd import CreateTransport, LatentSIV3, SecondStageSampler, Sampler
 from lam_slide_amd.synthetic import seeded_state_dict
 from oracle import harness, latent_net, transport as otr
