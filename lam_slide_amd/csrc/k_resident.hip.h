@@ -25,6 +25,7 @@
 #pragma once
 #include "common.hip.h"
 #include "k_small.hip.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
@@ -501,110 +502,141 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
                 // this lane's 4 (x2 key tiles) scores and the three other row groups of the column, Ot = V^T P^T with P taken straight from
                 // the accumulator registers as the B operand (k slot j of row group g: key 4g + j for j < 4, key 16 + 4g + j - 4 otherwise) and
                 // V^T fragments in the same key order from transposed LDS reads (ds_read_b64_tr_b16).
-                const int QT = (S + 15) >> 4;
-                for (int unit = wave; unit < n_seq * RES_H * QT; unit += RES_NW) {
-                    const int qt = unit % QT, hh = (unit / QT) & 3, seq = unit / (QT * RES_H);
-                    const int n0 = seq * qbase_mul;  // token of position p: n0 + p * sstride
-                    const int pq = 16 * qt + r16;
-                    const u16 *qp = qs_ + (size_t)(n0 + min(pq, S - 1) * sstride) * RES_QS + hh * RES_HD + 8 * g4;
-                    const bf16x8 qf = as_bf16x8(*reinterpret_cast<const u32x4 *>(qp));
-                    f32x4v sc[2];
+                // Two units per pass and every LDS read of both (q, k, V^T: none depends on the softmax) requested before the first MFMA: the
+                // phase is a latency chain (LDS -> MFMA -> exchange -> exp -> MFMA -> store), two independent chains fill each other's gaps.
+                const int QT = (S + 15) >> 4, n_units = n_seq * RES_H * QT;
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                for (int unit0 = wave; unit0 < n_units; unit0 += 2 * RES_NW) {
+                    int n0[2], pq[2], hh[2];
+                    bool on[2];
+                    bf16x8 qf[2], kf[2][2];
+                    s16x4 vt[2][2][2];
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
-                        const int pk = min(16 * kt + r16, S - 1);
-                        const bf16x8 kf = as_bf16x8(*reinterpret_cast<const u32x4 *>(qs_ + (size_t)(n0 + pk * sstride) * RES_QS + RES_HHD + hh * RES_HD + 8 * g4));
-                        sc[kt] = mfma16(kf, qf, f32x4v{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (16 * kt + 4 * g4 + e >= S) sc[kt][e] = -INFINITY;
-                    }
-                    float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
-                    mx = col_max4(mx);
-                    float pe[8], sum = 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pe[e] = __builtin_amdgcn_exp2f(sc[e >> 2][e & 3] - mx);
-                        sum += pe[e];
-                    }
-                    sum = col_sum4(sum);
-                    const u32x4 pw = {pack2(pe[0], pe[1]), pack2(pe[2], pe[3]), pack2(pe[4], pe[5]), pack2(pe[6], pe[7])};
-                    const float inv = 1.0f / sum;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        // transposed read: lane 4 q' + p' of a 16-lane group supplies row q' (key 4 g + q'), columns 4 p' .. 4 p' + 3 of the block
-                        typedef __attribute__((ext_vector_type(8))) short s16x8;
-                        s16x4 vt[2];
+                    for (int u = 0; u < 2; ++u) {
+                        const int unit = unit0 + u * RES_NW;
+                        on[u] = unit < n_units;  // (wave-uniform; an absent second unit recomputes the first and stores nothing)
+                        const int un = on[u] ? unit : unit0;
+                        const int qt = un % QT, seq = un / (QT * RES_H);
+                        hh[u] = (un / QT) & 3;
+                        n0[u] = seq * qbase_mul;  // token of position p: n0 + p * sstride
+                        pq[u] = 16 * qt + r16;
+                        qf[u] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qs_ + (size_t)(n0[u] + min(pq[u], S - 1) * sstride) * RES_QS + hh[u] * RES_HD + 8 * g4));
 #pragma unroll
                         for (int kt = 0; kt < 2; ++kt) {
-                            const int pk = min(16 * kt + 4 * g4 + (r16 >> 2), S - 1);
-                            const u16 *vp = qs_ + (size_t)(n0 + pk * sstride) * RES_QS + 2 * RES_HHD + hh * RES_HD + 16 * dt + 4 * (r16 & 3);
-                            vt[kt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vp));
+                            const int pk = min(16 * kt + r16, S - 1);
+                            kf[u][kt] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qs_ + (size_t)(n0[u] + pk * sstride) * RES_QS + RES_HHD + hh[u] * RES_HD + 8 * g4));
                         }
-                        const s16x8 vv = {vt[0][0], vt[0][1], vt[0][2], vt[0][3], vt[1][0], vt[1][1], vt[1][2], vt[1][3]};
-                        const f32x4v o = mfma16(__builtin_bit_cast(bf16x8, vv), as_bf16x8(pw), f32x4v{0.f, 0.f, 0.f, 0.f});
-                        if (pq < S) {
-                            const int n = n0 + pq * sstride, zc = hh * RES_HD + 16 * dt + 4 * g4;
-                            const u32x2 pk2 = {pack2(o[0] * inv, o[1] * inv), pack2(o[2] * inv, o[3] * inv)};
-                            *reinterpret_cast<u32x2 *>(zs + (size_t)n * 768 + res_swz(n, zc >> 3) + (zc & 4) * 2) = pk2;
-                        }
+                        // transposed reads: lane 4 q' + p' of a 16-lane group supplies row q' (key 4 g + q'), columns 4 p' .. 4 p' + 3 of the block
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                            for (int kt = 0; kt < 2; ++kt) {
+                                const int pk = min(16 * kt + 4 * g4 + (r16 >> 2), S - 1);
+                                const u16 *vp = qs_ + (size_t)(n0[u] + pk * sstride) * RES_QS + 2 * RES_HHD + hh[u] * RES_HD + 16 * dt + 4 * (r16 & 3);
+                                vt[u][dt][kt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vp));
+                            }
                     }
-                }
-            } else {
-                // short sequences (S <= 8): one lane per (query token, head), fp32 probabilities.  The head's 32 channels are walked in four
-                // 8-channel chunks (scores first, then the weighted sum chunk by chunk): ~40 live registers instead of q[32] + o[32], which
-                // this phase does not have beside the 128 weight registers that are in flight for linear2 and the next linear1
-                for (int item = tid; item < n_t * RES_H; item += NT) {
-                    const int n = item >> 2, hh = item & 3;
-                    const int k0 = temporal ? n % L : (n / L) * L;
-                    const u16 *qp = qs_ + (size_t)n * RES_QS + hh * RES_HD;
-                    const u16 *kp = qs_ + (size_t)k0 * RES_QS + RES_HHD + hh * RES_HD;  // key j: kp + j * sstride * RES_QS; value: + RES_HHD
-                    float dot[8];
+                    f32x4v sc[2][2];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dot[j] = 0.0f;
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const u32x4 qw = *reinterpret_cast<const u32x4 *>(qp + 8 * c);
+                        for (int kt = 0; kt < 2; ++kt) sc[u][kt] = mfma16(kf[u][kt], qf[u], f32x4v{0.f, 0.f, 0.f, 0.f});
+                    u32x4 pw[2];
+                    float inv[2];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            if (j >= S) break;  // (uniform)
-                            const u32x4 w = *reinterpret_cast<const u32x4 *>(kp + (size_t)j * sstride * RES_QS + 8 * c);
+                    for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                dot[j] = fmaf(__uint_as_float(qw[k] << 16), __uint_as_float(w[k] << 16), dot[j]);
-                                dot[j] = fmaf(__uint_as_float(qw[k] & 0xffff0000u), __uint_as_float(w[k] & 0xffff0000u), dot[j]);
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (16 * kt + 4 * g4 + e >= S) sc[u][kt][e] = -INFINITY;
+                        float mx = fmaxf(fmaxf(fmaxf(sc[u][0][0], sc[u][0][1]), fmaxf(sc[u][0][2], sc[u][0][3])),
+                                         fmaxf(fmaxf(sc[u][1][0], sc[u][1][1]), fmaxf(sc[u][1][2], sc[u][1][3])));
+                        mx = col_max4(mx);
+                        float pe[8], sum = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            pe[e] = __builtin_amdgcn_exp2f(sc[u][e >> 2][e & 3] - mx);
+                            sum += pe[e];
+                        }
+                        sum = col_sum4(sum);
+                        pw[u] = u32x4{pack2(pe[0], pe[1]), pack2(pe[2], pe[3]), pack2(pe[4], pe[5]), pack2(pe[6], pe[7])};
+                        inv[u] = 1.0f / sum;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const s16x8 vv = {vt[u][dt][0][0], vt[u][dt][0][1], vt[u][dt][0][2], vt[u][dt][0][3],
+                                              vt[u][dt][1][0], vt[u][dt][1][1], vt[u][dt][1][2], vt[u][dt][1][3]};
+                            const f32x4v o = mfma16(__builtin_bit_cast(bf16x8, vv), as_bf16x8(pw[u]), f32x4v{0.f, 0.f, 0.f, 0.f});
+                            if (on[u] && pq[u] < S) {
+                                const int n = n0[u] + pq[u] * sstride, zc = hh[u] * RES_HD + 16 * dt + 4 * g4;
+                                const u32x2 pk2 = {pack2(o[0] * inv[u], o[1] * inv[u]), pack2(o[2] * inv[u], o[3] * inv[u])};
+                                *reinterpret_cast<u32x2 *>(zs + (size_t)n * 768 + res_swz(n, zc >> 3) + (zc & 4) * 2) = pk2;
                             }
                         }
-                    }
-                    float mx = dot[0];
+                }
+            } else {
+                // short sequences (S <= 8): FOUR lanes (one DPP quad) per (query token, head), each owning 8 of the head's 32 channels: the
+                // partial dot products meet in two quad exchanges, the softmax is computed redundantly, each lane finishes and stores its own
+                // 16-byte chunk.  (One lane per item left 160 of 512 lanes busy on a 4x longer dependent chain; fp32 probabilities.)
+                // Compiled for SP = 2, 4 or 8 key slots (slots >= S re-read the last key and get probability 0) so that every LDS read of
+                // an item - q, SP keys, SP values - is requested before the first use: one LDS latency instead of 1 + 2 S.
+                auto quad_attention = [&](auto sp_tag) {
+                    constexpr int SP = decltype(sp_tag)::value;
+                    for (int it = tid; it < n_t * RES_H * 4; it += NT) {
+                        const int c = it & 3, hh = (it >> 2) & 3, n = it >> 4;
+                        const int k0 = temporal ? n % L : (n / L) * L;
+                        const u16 *kp = qs_ + (size_t)k0 * RES_QS + RES_HHD + hh * RES_HD + 8 * c;  // key j: + j * sstride * RES_QS; value: + RES_HHD
+                        const u32x4 qw = *reinterpret_cast<const u32x4 *>(qs_ + (size_t)n * RES_QS + hh * RES_HD + 8 * c);
+                        u32x4 kw[SP], vw[SP];
 #pragma unroll
-                    for (int j = 1; j < 8; ++j)
-                        if (j < S) mx = fmaxf(mx, dot[j]);
-                    float sum = 0.0f;
+                        for (int j = 0; j < SP; ++j) {
+                            const u16 *kj = kp + (size_t)min(j, S - 1) * sstride * RES_QS;
+                            kw[j] = *reinterpret_cast<const u32x4 *>(kj);
+                            vw[j] = *reinterpret_cast<const u32x4 *>(kj + RES_HHD);
+                        }
+                        float dot[SP];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        dot[j] = j < S ? __builtin_amdgcn_exp2f(dot[j] - mx) : 0.0f;
-                        sum += dot[j];
-                    }
-                    const float inv = 1.0f / sum;
+                        for (int j = 0; j < SP; ++j) {
+                            float d = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                            for (int k = 0; k < 4; ++k) {
+                                d = fmaf(__uint_as_float(qw[k] << 16), __uint_as_float(kw[j][k] << 16), d);
+                                d = fmaf(__uint_as_float(qw[k] & 0xffff0000u), __uint_as_float(kw[j][k] & 0xffff0000u), d);
+                            }
+                            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, true));
+                            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, true));
+                            dot[j] = j < S ? d : -INFINITY;
+                        }
+                        float mx = dot[0];
+#pragma unroll
+                        for (int j = 1; j < SP; ++j) mx = fmaxf(mx, dot[j]);
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < SP; ++j) {
+                            dot[j] = __builtin_amdgcn_exp2f(dot[j] - mx);
+                            sum += dot[j];
+                        }
+                        const float inv = 1.0f / sum;
                         float o[8];
 #pragma unroll
                         for (int d = 0; d < 8; ++d) o[d] = 0.0f;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            if (j >= S) break;
-                            const u32x4 w = *reinterpret_cast<const u32x4 *>(kp + (size_t)j * sstride * RES_QS + RES_HHD + 8 * c);
+                        for (int j = 0; j < SP; ++j)
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                o[2 * k] = fmaf(dot[j], __uint_as_float(w[k] << 16), o[2 * k]);
-                                o[2 * k + 1] = fmaf(dot[j], __uint_as_float(w[k] & 0xffff0000u), o[2 * k + 1]);
+                                o[2 * k] = fmaf(dot[j], __uint_as_float(vw[j][k] << 16), o[2 * k]);
+                                o[2 * k + 1] = fmaf(dot[j], __uint_as_float(vw[j][k] & 0xffff0000u), o[2 * k + 1]);
                             }
-                        }
                         const u32x4 w = {pack2(o[0] * inv, o[1] * inv), pack2(o[2] * inv, o[3] * inv), pack2(o[4] * inv, o[5] * inv), pack2(o[6] * inv, o[7] * inv)};
                         *reinterpret_cast<u32x4 *>(zs + (size_t)n * 768 + res_swz(n, 4 * hh + c)) = w;
                     }
-                }
+                };
+                if (S <= 2) quad_attention(std::integral_constant<int, 2>{});
+                else if (S <= 4) quad_attention(std::integral_constant<int, 4>{});
+                else quad_attention(std::integral_constant<int, 8>{});
             }
             res_barrier();
             RES_STAMP(2);
