@@ -303,6 +303,14 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
             const float4 t = *reinterpret_cast<const float4 *>(hp + 4 * c4);
             v[4 * c4] = t.x; v[4 * c4 + 1] = t.y; v[4 * c4 + 2] = t.z; v[4 * c4 + 3] = t.w;
         }
+        float4 sc[4], sf[4];  // modulation rows: requested with the row itself, used two reductions later
+        if (mode != 0) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                sc[c4] = *reinterpret_cast<const float4 *>(scale + col + 4 * c4);
+                sf[c4] = *reinterpret_cast<const float4 *>(shift + col + 4 * c4);
+            }
+        }
         float s = 0.0f;
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) s += (v[4 * c4] + v[4 * c4 + 1]) + (v[4 * c4 + 2] + v[4 * c4 + 3]);
@@ -317,11 +325,10 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
         if (mode != 0) {
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                const float4 sc = *reinterpret_cast<const float4 *>(scale + col + 4 * c4), sf = *reinterpret_cast<const float4 *>(shift + col + 4 * c4);
-                v[4 * c4] = fmaf(v[4 * c4] * rstd, 1.0f + sc.x, sf.x);
-                v[4 * c4 + 1] = fmaf(v[4 * c4 + 1] * rstd, 1.0f + sc.y, sf.y);
-                v[4 * c4 + 2] = fmaf(v[4 * c4 + 2] * rstd, 1.0f + sc.z, sf.z);
-                v[4 * c4 + 3] = fmaf(v[4 * c4 + 3] * rstd, 1.0f + sc.w, sf.w);
+                v[4 * c4] = fmaf(v[4 * c4] * rstd, 1.0f + sc[c4].x, sf[c4].x);
+                v[4 * c4 + 1] = fmaf(v[4 * c4 + 1] * rstd, 1.0f + sc[c4].y, sf[c4].y);
+                v[4 * c4 + 2] = fmaf(v[4 * c4 + 2] * rstd, 1.0f + sc[c4].z, sf[c4].z);
+                v[4 * c4 + 3] = fmaf(v[4 * c4 + 3] * rstd, 1.0f + sc[c4].w, sf[c4].w);
             }
         } else {
 #pragma unroll
@@ -649,24 +656,35 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
                 f32x4v acc[NNT];
 #pragma unroll
                 for (int nt = 0; nt < NNT; ++nt) acc[nt] = f32x4v{bq.x, bq.y, bq.z, bq.w};
+                // token operand through a 3-deep register ring, two k-steps ahead of the MFMAs (read where it is used, hipcc emits
+                // read / lgkmcnt(0) / MFMA per k-step: twelve exposed LDS latencies); the residual rows are requested up front too
+                auto zread = [&](int ks, bf16x8 *dst) {
 #pragma unroll
-                for (int ks = 0; ks < 12; ++ks)
+                    for (int nt = 0; nt < NNT; ++nt)
+                        dst[nt] = as_bf16x8(*reinterpret_cast<const u32x4 *>(zs + (size_t)(16 * nt + r16) * 768 + res_swz(16 * nt + r16, 4 * ks + g4)));
+                };
+                bf16x8 zf[3][NNT];
+                zread(0, zf[0]);
+                zread(1, zf[1]);
+                float4 hv[NNT];
 #pragma unroll
-                    for (int nt = 0; nt < NNT; ++nt) {
-                        const bf16x8 zf = as_bf16x8(*reinterpret_cast<const u32x4 *>(zs + (size_t)(16 * nt + r16) * 768 + res_swz(16 * nt + r16, 4 * ks + g4)));
-                        acc[nt] = mfma16(w2f[ks], zf, acc[nt]);
-                    }
+                for (int nt = 0; nt < NNT; ++nt) hv[nt] = *reinterpret_cast<const float4 *>(hs + (size_t)min(16 * nt + r16, n_t - 1) * RES_HS + f0 + 4 * g4);
+#pragma unroll
+                for (int ks = 0; ks < 12; ++ks) {
+                    if (ks + 2 < 12) zread(ks + 2, zf[(ks + 2) % 3]);
+#pragma unroll
+                    for (int nt = 0; nt < NNT; ++nt) acc[nt] = mfma16(w2f[ks], zf[ks % 3][nt], acc[nt]);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NNT; ++nt) {
                     const int n = 16 * nt + r16;
                     if (n < n_t) {
                         float *hp = hs + (size_t)n * RES_HS + f0 + 4 * g4;
-                        float4 hv = *reinterpret_cast<float4 *>(hp);
-                        hv.x = fmaf(gt.x, acc[nt][0], hv.x);
-                        hv.y = fmaf(gt.y, acc[nt][1], hv.y);
-                        hv.z = fmaf(gt.z, acc[nt][2], hv.z);
-                        hv.w = fmaf(gt.w, acc[nt][3], hv.w);
-                        *reinterpret_cast<float4 *>(hp) = hv;
+                        hv[nt].x = fmaf(gt.x, acc[nt][0], hv[nt].x);
+                        hv[nt].y = fmaf(gt.y, acc[nt][1], hv[nt].y);
+                        hv[nt].z = fmaf(gt.z, acc[nt][2], hv[nt].z);
+                        hv[nt].w = fmaf(gt.w, acc[nt][3], hv[nt].w);
+                        *reinterpret_cast<float4 *>(hp) = hv[nt];
                     }
                 }
             }
