@@ -72,7 +72,10 @@ __global__ void __launch_bounds__(256) k_res_pack(u16 *wout, float *pout, ResPac
 
 struct ResArgs {
     float *x;                 // [B][n_t][C] state, updated in place
-    const float *cond_emb;    // [B][n_t][D] fp32: cond_to_emb(x_cond) + biases + mask embedding (k_embed MODE 0)
+    float *cond_emb;          // [B][n_t][D] fp32 scratch: cond_to_emb(x_cond) + biases + mask embedding, written by the kernel's prologue
+    const float *x_cond;      // [B][n_t][C]
+    const int64_t *mask;      // [B][n_t]
+    const float *cond_w, *cond_b, *x_in_b, *mask_emb;  // [D][C], [D], [D], [2][D]   (latent_si_v31.py:172)
     const float *mods;        // [n_steps][rows][MODW] modulation tables of every step of this launch (rows = B, or 1 when shared)
     long mods_step_stride;    // floats between steps
     int mods_traj_stride;     // floats between trajectories (0: one shared row)
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
 #define RES_OPAQUE_LANE() asm volatile("" : "+v"(tid), "+v"(lane), "+v"(r16), "+v"(g4))
     const int b = blockIdx.x, n_t = A.n_t, C = A.C, T = A.T, L = A.L;
     const size_t xoff = (size_t)b * n_t * C;
-    const float *cond = A.cond_emb + (size_t)b * n_t * D;
+    float *cond = A.cond_emb + (size_t)b * n_t * D;
 
 #ifdef LSL_EXPERIMENTS
     if (A.skip) {  // the phase-skipping probes read buffers nobody wrote: make them zeros, not whatever the previous kernel left in LDS
@@ -223,6 +226,34 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
     // embedding (fp32 MFMA, features on accumulator rows): wave w owns features 16 w .. + 15 of all tokens.  Its slice of the input
     // projection and of the conditioning embedding (the accumulators' initial value) is the same for every state update, but 20 registers
     // are not free across the block loop: they are re-requested (L2 hits) in the head phase of the previous update
+    // the conditioning embedding itself is computed here, once per launch, on the same fp32 MFMA tiles (it used to be a launch of the
+    // general path's persistent embedding kernel: 21 us for 800 tokens): every lane stores the float4 it will re-read
+    {
+        float4 cw[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = 16 * j + 4 * g4;
+            cw[j] = *reinterpret_cast<const float4 *>(A.cond_w + (size_t)(16 * wave + r16) * C + min(c, C - 4));
+            if (c >= C) cw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4 cb = *reinterpret_cast<const float4 *>(A.cond_b + 16 * wave + 4 * g4), xb = *reinterpret_cast<const float4 *>(A.x_in_b + 16 * wave + 4 * g4);
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) {
+            const int n = 16 * nt + r16, nn = min(n, n_t - 1);
+            const float *xr = A.x_cond + ((size_t)b * n_t + nn) * C;
+            const float4 me = *reinterpret_cast<const float4 *>(A.mask_emb + (A.mask[(size_t)b * n_t + nn] != 0 ? D : 0) + 16 * wave + 4 * g4);
+            f32x4v acc = {(cb.x + xb.x) + me.x, (cb.y + xb.y) + me.y, (cb.z + xb.z) + me.z, (cb.w + xb.w) + me.w};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (16 * j >= C) break;  // (uniform)
+                const int c = 16 * j + 4 * g4;
+                float4 xv = *reinterpret_cast<const float4 *>(xr + min(c, C - 4));
+                if (c >= C) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = mfma16_f32x4(cw[j], xv, acc);
+            }
+            if (n < n_t) *reinterpret_cast<float4 *>(cond + (size_t)n * D + 16 * wave + 4 * g4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
     float4 wxf[2], cnd[NNT];
     auto load_embed_operands = [&]() {
 #pragma unroll

@@ -167,6 +167,54 @@ __global__ void __launch_bounds__(256) k_dense_tiled(float *out, const float *in
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same contract once more for the SHORT chains of tiny GEMMs in front of the trajectory-resident kernel (rows = state updates x
+// conditioning rows <= a few hundred, I = 128 / 256): there each launch is pure latency, and the 64 x 64 FMA tiles above put a whole
+// 256-deep k loop on two or eight workgroups (13-22 us per launch, five launches per sampling call).  Here a workgroup owns a 32 x 32
+// output tile, its four waves each take a quarter of k on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 multiply-add),
+// every operand byte of a wave is requested before its first MFMA, and the four partial tiles meet in LDS in a fixed order.
+// One kernel for every batch size (the choice depends on the model only), so a trajectory's tables do not depend on its batch.
+typedef __attribute__((ext_vector_type(16))) float f32x16_d;
+template <bool PRE_SILU, bool POST_SILU, int KQ>  // KQ = I / 4 (k per wave): 32 or 64
+__global__ void __launch_bounds__(256) k_dense_mfma(float *out, const float *in, const float *W, const float *bias, const float *add,
+                                                    int rows, int I, int O, int add_stride, int add_mod) {
+    __shared__ float Ps[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int r0 = blockIdx.y * 32, o0 = blockIdx.x * 32;
+    const float *ap = in + (size_t)min(r0 + r, rows - 1) * I + wave * KQ + 4 * hf;
+    const float *wp = W + (size_t)min(o0 + r, O - 1) * I + wave * KQ + 4 * hf;
+    float4 a[KQ / 8], w[KQ / 8];  // lane (r, hf): k = 8 j + 4 hf .. + 3 of the wave's slice, the same k order for both operands
+#pragma unroll
+    for (int j = 0; j < KQ / 8; ++j) {
+        a[j] = *reinterpret_cast<const float4 *>(ap + 8 * j);
+        w[j] = *reinterpret_cast<const float4 *>(wp + 8 * j);
+    }
+    f32x16_d acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KQ / 8; ++j) {
+        float4 av = a[j];
+        if (PRE_SILU) av = make_float4(silu(av.x), silu(av.y), silu(av.z), silu(av.w));
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w[j].w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Ps[wave][acc_row(e, hf)][r] = acc[e];  // (row of the tile = input row, column = output)
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q, row = idx >> 5, col = idx & 31, b = r0 + row, o = o0 + col;
+        if (b >= rows || o >= O) continue;
+        float v = ((Ps[0][row][col] + Ps[1][row][col]) + Ps[2][row][col]) + Ps[3][row][col] + bias[o];
+        if (add) v += add[(size_t)(add_mod ? b % add_mod : b) * add_stride + o];
+        if (POST_SILU) v = silu(v);
+        out[(size_t)b * O + o] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Small-K projection C -> D (x_in / cond_to_emb, latent_si_v31.py:172), exact fp32 FMA chains over c.
 //   MODE 0 (once per sample): out = in @ W^T + bias + bias2 + mask_emb[mask]      (cond_to_emb part)
 //   MODE 1 (every evaluation): out = in @ W^T + base                              (x_in part + cached)

@@ -499,6 +499,19 @@ void launch_dense(float *out, const float *in, const float *W, const float *bias
         hipLaunchKernelGGL((k_dense_rows<PRE, POST>), dim3((O + 3) / 4), dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride, add_mod);
 }
 
+// the short GEMM chains in front of the trajectory-resident kernel (k_dense_mfma: latency-optimised; one kernel for any row count)
+template <bool PRE, bool POST>
+void launch_dense_small(float *out, const float *in, const float *W, const float *bias, const float *add, int rows, int I, int O,
+                        int add_stride, hipStream_t st, int add_mod = 0) {
+    const dim3 grid((O + 31) / 32, (rows + 31) / 32);
+    if (I == 128)
+        hipLaunchKernelGGL((k_dense_mfma<PRE, POST, 32>), grid, dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride, add_mod);
+    else if (I == 256)
+        hipLaunchKernelGGL((k_dense_mfma<PRE, POST, 64>), grid, dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride, add_mod);
+    else
+        launch_dense<PRE, POST>(out, in, W, bias, add, rows, I, O, add_stride, st, false, add_mod);
+}
+
 // ---- pieces of one evaluation ----------------------------------------------------------------------
 
 // conditioning vector -> all modulation tables for `rows` trajectories (latent_si_v31.py:176-178,
@@ -714,15 +727,16 @@ int resident_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int n
     const bool have_y = io->y != nullptr;
     const ResWorkspace ws = carve_resident(m, (char *)workspace, B, T, L, have_y);
     const int rows = have_y ? B : 1;
-    launch_embed<0>(ws.cond_emb, io->x_cond, w.cond_w, w.cond_b, w.x_in_b, w.mask_emb, io->mask, nullptr, B * n_t, d.in_dim, D, st);
-    LSL_CHECK_LAUNCH("cond_embed");
     if (have_y) {
-        launch_dense<false, true>(ws.hid, io->y, w.vec_w1, w.vec_b1, nullptr, B, d.vec_in_dim, D, 0, st);
-        launch_dense<false, false>(ws.yemb, ws.hid, w.vec_w2, w.vec_b2, nullptr, B, D, D, 0, st);
+        launch_dense_small<false, true>(ws.hid, io->y, w.vec_w1, w.vec_b1, nullptr, B, d.vec_in_dim, D, 0, st);
+        launch_dense_small<false, false>(ws.yemb, ws.hid, w.vec_w2, w.vec_b2, nullptr, B, D, D, 0, st);
         LSL_CHECK_LAUNCH("vec_in");
     }
     ResArgs a;
     a.cond_emb = ws.cond_emb;
+    a.x_cond = io->x_cond;
+    a.mask = (const int64_t *)io->mask;
+    a.cond_w = w.cond_w; a.cond_b = w.cond_b; a.x_in_b = w.x_in_b; a.mask_emb = w.mask_emb;
     a.x = io->x;
     a.mods = ws.mods;
     a.mods_step_stride = (long)rows * m->MODW;
@@ -762,9 +776,9 @@ int resident_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int n
         // conditioning vector -> modulation tables of the group's steps (latent_si_v31.py:176-178, mmdit.py:184-197); the tiled kernel
         // is used for any row count, so a trajectory's tables do not depend on the batch it is sampled in
         hipLaunchKernelGGL(k_time_features_steps, dim3((rt * 128 + 255) / 256), dim3(256), 0, st, ws.tfeat, tt, ns, rows, w.time_freqs);
-        launch_dense<false, true>(ws.hid, ws.tfeat, w.time_w1, w.time_b1, nullptr, rt, 256, D, 0, st);
-        launch_dense<false, false>(ws.vec, ws.hid, w.time_w2, w.time_b2, have_y ? ws.yemb : nullptr, rt, D, D, D, st, false, have_y ? B : 0);
-        launch_dense<true, false>(ws.mods, ws.vec, w.mod_w, w.mod_b, nullptr, rt, D, m->MODW, 0, st);
+        launch_dense_small<false, true>(ws.hid, ws.tfeat, w.time_w1, w.time_b1, nullptr, rt, 256, D, 0, st);
+        launch_dense_small<false, false>(ws.vec, ws.hid, w.time_w2, w.time_b2, have_y ? ws.yemb : nullptr, rt, D, D, D, st, have_y ? B : 0);
+        launch_dense_small<true, false>(ws.mods, ws.vec, w.mod_w, w.mod_b, nullptr, rt, D, m->MODW, 0, st);
         LSL_CHECK_LAUNCH("modulation");
         a.step0 = (unsigned)s0;
         a.n_steps = ns;
