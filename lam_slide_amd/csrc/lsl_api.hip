@@ -257,6 +257,17 @@ int device_cus();
 template <int MODE>
 int launch_embed(float *out, const float *in, const float *W, const float *b, const float *b2, const float *me,
                  const int64_t *mask, const float *base, int n, int C, int D, hipStream_t st) {
+    if (C > 32 && C % 8 == 0 && C <= 128 && D % 32 == 0) {  // wide inputs: fp32 MFMA form (k_embed_mfma)
+        const int tpw = 3, ngrp = (D / 32 + tpw - 1) / tpw;
+        const long units = (long)((n + 31) / 32) * ngrp;
+        const dim3 g((unsigned)((units + 3) / 4));
+        switch (C / 8) {
+#define LSL_EMB_CASE(CK) case CK: hipLaunchKernelGGL((k_embed_mfma<MODE, CK>), g, dim3(256), 0, st, out, in, W, b, b2, me, mask, base, n, C, D, tpw); return 0;
+            LSL_EMB_CASE(5) LSL_EMB_CASE(6) LSL_EMB_CASE(7) LSL_EMB_CASE(8) LSL_EMB_CASE(9) LSL_EMB_CASE(10) LSL_EMB_CASE(11) LSL_EMB_CASE(12)
+            LSL_EMB_CASE(13) LSL_EMB_CASE(14) LSL_EMB_CASE(15) LSL_EMB_CASE(16)
+#undef LSL_EMB_CASE
+        }
+    }
     const dim3 grid(std::min((n + EMB_TOK - 1) / EMB_TOK, 2 * device_cus())), blk(256);  // persistent: weights fetched once per workgroup
     if (C <= 32) hipLaunchKernelGGL((k_embed<32, MODE, 4>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
     else if (C <= 64) hipLaunchKernelGGL((k_embed<64, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
