@@ -118,7 +118,7 @@ int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L);
 
 /* Which kernel family lsl_sample uses for trajectories of T x L tokens of this model: 0 = the general path (one launch per kernel per
  * sub-block, any shape), 1 = the trajectory-resident path (csrc/k_resident.hip.h: models of the pedestrian family - hidden 128, 4 heads
- * of 32, mlp 256 - with T*L <= 48: one workgroup per trajectory runs whole groups of state updates in a single launch).  The answer
+ * of 32, mlp 256 - with T*L <= 48 and T, L <= 32: one workgroup per trajectory runs whole groups of state updates in a single launch).  The answer
  * depends on the model and on T, L only, never on the batch, so a trajectory's result does not depend on what it is batched with. */
 int32_t lsl_sampler_path(const lsl_model *m, int32_t T, int32_t L);
 
