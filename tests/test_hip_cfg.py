@@ -355,3 +355,55 @@ def test_resident_kernel_rerun_bits(shape, dev):
     assert s.last_kernels == "resident" and torch.isfinite(ref).all()
     differ = sum(0 if torch.equal(fn(init.to(dev), net.forward, **mk)[-1], ref) else 1 for _ in range(30))
     assert differ == 0, f"{differ}/30 reruns differ"
+
+
+FULL_SHAPES = {
+    # BASELINE.json configs[3] / [4] at their true token counts (the benchmark's shapes), few state updates
+    "peptide_T1000_L2": (dict(depth=7, in_dim=96, hidden_size=384, num_heads=16, mlp_ratio=4), 1000, 2, None, "SDE", 5e-4),
+    "nba_T20_L8": (dict(depth=6, in_dim=32, hidden_size=256, num_heads=16, mlp_ratio=4, vec_in_dim=256, normalize=True), 20, 8, 256, "ODE", 8e-4),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SHAPES))
+def test_full_size_shapes_of_cfg4_and_cfg5(name, dev):
+    """The peptide (T = 1000: the long-sequence attention kernel, 24-wide heads padded to 32, 96 input channels on the fp32-MFMA
+    embedding) and NBA (16-wide heads, class vector) models at the token counts of the benchmark: one network evaluation and a short
+    sampler run against the oracle, and a trajectory's bits independent of the batch it is sampled in."""
+    from lam_slide_amd import CreateTransport, Sampler
+    from oracle import harness, latent_net, transport as otr
+    kw, T, L, V, method, bar = FULL_SHAPES[name]
+    net, sh, p = _net(kw, 11, dev)
+    B, C = 2, kw["in_dim"]
+    g = torch.Generator().manual_seed(9)
+    lat, init = torch.randn(B, T, L, C, generator=g), torch.randn(B, T, L, C, generator=g)
+    y = torch.randn(B, V, generator=g) if V else None
+    xc, m = harness.setup_conditioning(lat, (0, 1) if T > 100 else (0, 5), True)
+    mk = {"x_cond": xc.to(dev), "x_cond_mask": m.to(dev)}
+    mko = {"x_cond": xc, "x_cond_mask": m}
+    if y is not None:
+        mk["y"], mko["y"] = y.to(dev), y
+    t = torch.tensor([0.3, 0.7])
+    got = net(init.to(dev), t.to(dev), **mk)
+    want = latent_net.forward(p, sh, init, t, **mko)
+    assert net.last_path == "hip"
+    parity(f"full.{name}.forward", rel_l2(got.cpu(), want), bar)
+    s = Sampler(CreateTransport("GVP", "data")(), fused=True)
+    if method == "ODE":
+        skw = {"sampling_method": "euler", "num_steps": 4}
+        run = lambda lo, hi: s.get_sample_fn("ODE", skw)(init[lo:hi].to(dev), net.forward, **{k: v[lo:hi] for k, v in mk.items()})[-1]
+        want_s = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init, xc, m, y, "ODE", skw)
+    else:
+        n = 4
+        noise = torch.randn(n - 1, B, T, L, C, generator=g)
+        run = lambda lo, hi: s.sample_sde(diffusion_form="linear", last_step="Mean", num_steps=n, noise=noise[:, lo:hi].to(dev))(
+            init[lo:hi].to(dev), net.forward, **{k: v[lo:hi] for k, v in mk.items()})[-1]
+
+        def model(xt, tt, **kw_):
+            return latent_net.forward(p, sh, xt, tt.to(xt.dtype), **kw_)
+
+        want_s = otr.sample_sde(otr.Transport("GVP", "data"), init, model, noise=list(noise), diffusion_form="linear", last_step="Mean", num_steps=n,
+                                single_eval=True, **mko)[-1]
+    full = run(0, B)
+    assert s.last_path == "fused" and torch.isfinite(full).all()
+    parity(f"full.{name}.sampler", rel_l2(full.cpu(), want_s), 1.4 * bar if T > 100 else bar)
+    assert torch.equal(full, torch.cat([run(0, 1), run(1, 2)]))
