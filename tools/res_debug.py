@@ -14,7 +14,7 @@ def case(T, L, C, norm, depth, B=5):
     net = LatentSIV3(reset_parameters=False, **kw); net.load_state_dict(p); net.to(dev)
     g = torch.Generator().manual_seed(5)
     lat, init = torch.randn(B, T, L, C, generator=g), torch.randn(B, T, L, C, generator=g)
-    xc, m = harness.setup_conditioning(lat, (0, min(3, T - 1)), True)
+    xc, m = harness.setup_conditioning(lat, (0, max(1, min(3, T - 1))), True)
     mk = {"x_cond": xc.to(dev), "x_cond_mask": m.to(dev)}
     for ns in (9,):
         skw = {"sampling_method": "euler", "num_steps": ns}
