@@ -503,7 +503,11 @@ void launch_dense(float *out, const float *in, const float *W, const float *bias
     // take the wave-per-output kernel (a coalesced GEMV, 8x faster at one row than the 64-row tile kernel).
     if (single && rows == 1 && I <= 512)
         hipLaunchKernelGGL((k_dense_rows<PRE, POST>), dim3((O + 3) / 4), dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride, add_mod);
-    else if (I % 4 == 0)
+    else if ((I == 128 || I == 256) && tune_int("LSL_DENSE_MFMA", 1)) {  // many rows, usual widths: the fp32 matrix pipe (k_dense_mfma)
+        const dim3 grid((O + 31) / 32, (rows + 31) / 32);
+        if (I == 128) hipLaunchKernelGGL((k_dense_mfma<PRE, POST, 32>), grid, dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride, add_mod);
+        else hipLaunchKernelGGL((k_dense_mfma<PRE, POST, 64>), grid, dim3(256), 0, st, out, in, W, bias, add, rows, I, O, add_stride, add_mod);
+    } else if (I % 4 == 0)
         hipLaunchKernelGGL((k_dense_tiled<PRE, POST>), dim3((O + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, out, in, W, bias, add, rows,
                            I, O, add_stride, add_mod);
     else
