@@ -1,3 +1,6 @@
+"""Checker script (test infrastructure, not collected by pytest): the trajectory-resident kernel against the oracle at the pedestrian
+shape, batch independence of a trajectory's bits, and wall time per 10-update call at B = 1 / 20 / 160 / 1280.
+Usage (GPU box): python tests/resident_check.py   (LSL_LIB=<path> selects another build of the library)"""
 import sys, time, os, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 from lam_slide_amd import _lib

@@ -1,6 +1,6 @@
 """Rerun determinism of the trajectory-resident kernel: the same sampling call repeated RERUNS times (default 40) per shape, count of
 results that differ from the first one (must be 0).  CASES="[(T, L, C, normalize, depth), ...]" selects shapes, LSL_LIB=<path> another
-build of the library.  Usage (GPU box): python tools/res_debug.py"""
+build of the library.  Usage (GPU box): python tests/resident_reruns.py"""
 import sys, os, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from lam_slide_amd import _lib
