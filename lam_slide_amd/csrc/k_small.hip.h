@@ -235,10 +235,21 @@ __global__ void __launch_bounds__(256) k_embed(float *out, const float *in, cons
         const int tg = DQ >= 256 ? 0 : threadIdx.x / DQ, d = ND * dq;
         const bool active = tg < groups;  // (threads beyond groups * DQ only help with the staging)
         float w[ND][CMAX];
+        if ((C & 3) == 0) {  // 16-byte loads (every shipped model): a quarter of the load instructions of the per-element form, which made
+                             // this prologue ~20 us of a 39 us launch at 23 000 tokens (md17 reference shape)
 #pragma unroll
-        for (int j = 0; j < ND; ++j)
+            for (int j = 0; j < ND; ++j)
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) w[j][c] = (active && c < C) ? W[(size_t)(d + j) * C + c] : 0.0f;
+                for (int c = 0; c < CMAX; c += 4) {
+                    const float4 w4 = (active && c < C) ? *reinterpret_cast<const float4 *>(W + (size_t)(d + j) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    w[j][c] = w4.x; w[j][c + 1] = w4.y; w[j][c + 2] = w4.z; w[j][c + 3] = w4.w;
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < ND; ++j)
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) w[j][c] = (active && c < C) ? W[(size_t)(d + j) * C + c] : 0.0f;
+        }
         float b0[ND];
 #pragma unroll
         for (int j = 0; j < ND; ++j) b0[j] = (MODE == 0 && active) ? bias[d + j] + bias2[d + j] : 0.0f;
