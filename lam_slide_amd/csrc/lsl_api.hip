@@ -394,7 +394,7 @@ bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 // 20-22: ping-pong halves (k_gemm_pp.hip.h).  Default (-1): 12 for linear1 (5 when K < 512 or not a multiple of 128, 6 when not a multiple of 64), 7 for linear2: the fastest pair measured on MI355X (profiles/r01_gemm_variants.txt lists
 // every variant that was tried, including the ones no longer compiled in).
 template <class Epi>
-int gemm_variant(int F, int K) {
+int gemm_variant(int F, int K, int N = 1 << 30) {
     static const int forced_all = tune_int("LSL_GEMM", -1);
     static const int forced_1 = tune_int("LSL_GEMM1", -1), forced_2 = tune_int("LSL_GEMM2", -1);  // per GEMM: linear1 / linear2
     const int forced_one = std::is_same<Epi, EpiLinear2>::value ? forced_2 : forced_1;
@@ -402,7 +402,20 @@ int gemm_variant(int F, int K) {
     // 256-wide feature tiles waste MFMA work when F is not a multiple of 256 (D = 128 / 384 models): use 128 x 128 there
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
     const int ragged_variant = std::is_same<Epi, EpiLinear2>::value && K % 64 == 0 ? 11 : 10;  // measured on the D = 384 / 128 models
-    return forced >= 0 ? forced : ragged ? ragged_variant : (std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 ? 12 : 5));
+    if (forced >= 0) return forced;
+    if (ragged) return ragged_variant;
+    // Small launches (one or two trajectories of the MD17 models, the reference's own B = 4 case): 256 x 256 tiles leave most of the chip
+    // idle or run two rounds for 1.2 rounds of work; 128 x 128 tiles (two workgroups per CU) fill it.  Measured (profiles/
+    // r02_experiments.txt): md17_bench B = 1 49.1 -> 38.0 ms per call, B = 2 63.0 -> 59.3, md17_ref B = 4 8.00 -> 7.65; from B = 4 of
+    // md17_bench on the large tiles win again.  The tile shape does not change any output bit (every element is the same k-ascending
+    // chain of 16-deep MFMA steps and the same epilogue arithmetic - checked by the batch-32-vs-batch-1 test at the headline shape),
+    // so this may depend on the launch size.
+    static const int small_rule = tune_int("LSL_SMALL_TILES", 1);
+    const long tiles256 = (long)((N + 255) / 256) * ((F + 255) / 256);
+    const int cus = device_cus();
+    if (small_rule && K % 64 == 0 && tiles256 * (std::is_same<Epi, EpiLinear2>::value ? 2 : 4) <= (long)cus * (std::is_same<Epi, EpiLinear2>::value ? 1 : 5))
+        return 11;  // linear2: tiles <= CUs / 2; linear1: tiles <= 1.25 CUs
+    return std::is_same<Epi, EpiLinear2>::value ? (K % 128 == 0 ? 7 : 15) : (K % 128 == 0 ? 12 : 5);
 }
 
 // linear2 can also write the next sub-block's LayerNorm + modulate (EpiLinear2::finish_rows) when it runs as the persistent
@@ -415,7 +428,7 @@ bool linear2_can_fuse_ln(int D, int N, int K2) {
 
 template <class Epi>
 void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi_in, hipStream_t st, int hhd = 32, bool rows = false) {
-    const int variant = gemm_variant<Epi>(F, K);
+    const int variant = gemm_variant<Epi>(F, K, N);
     static const int probe = tune_int("LSL_PROBE", 0);
     static const int stagger = tune_int("LSL_STAGGER", 0);
     GemmArgs g{W, X, F, N, K, rows ? 1 : 0, stagger, probe};
