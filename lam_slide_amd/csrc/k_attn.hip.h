@@ -23,6 +23,8 @@ struct AttnArgs {
     // token of (seq, pos) = (seq / inner) * outer_stride + (seq % inner) + pos * pos_stride
     int inner, outer_stride, pos_stride;
     int nt;          // streaming stores for the output (common.hip.h: store8)
+    int hd;          // true head_dim (<= HDP).  hd < HDP (peptide: 24 of 32): the padding channels of v are zero, and k_attention_rows
+                     // turns channel hd of the staged V into ones, so that row hd of O^T = V^T P^T IS the softmax denominator
 };
 
 template <int HDP>
@@ -162,6 +164,9 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
     const int r = lane & 31, hf = lane >> 5;
     const int S = a.S;
     const int nkt = NKT > 0 ? NKT : (S + 31) >> 5, Sp = nkt * 32;  // NKT = 0: key-tile count known at run time only
+    // padded heads (hd = 24 of HDP = 32): the denominator comes out of the PV product (a column of ones in V's padding) instead of a
+    // third MFMA against an all-ones operand: 6 instead of 8 MFMAs per (query tile, key tile) in a kernel whose MFMA and VALU time add
+    const bool ones_col = HDP == 32 && a.hd == 24;  // (wave-uniform; acc_row(12, 0) == 24)
     const int item_local = wave / WPI, wsub = wave % WPI;
     // heads of one sequence share 128-byte lines of the token rows: keep neighbouring (sequence, head) items on one XCD
     const long item = (long)xcd_remap(blockIdx.x, gridDim.x) * ITEMS + item_local;
@@ -190,6 +195,10 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
                 const size_t off = (size_t)row * a.pos_stride * rs + ch * 8;
                 kv = *reinterpret_cast<const u32x4 *>(kbase + off);
                 vv = *reinterpret_cast<const u32x4 *>(vbase + off);
+                if (ones_col && ch == a.hd / 8) {  // channel hd (head dims are multiples of 8) of a REAL key row := 1.0 (bf16 0x3F80)
+                    const int el = (a.hd & 7) >> 1;
+                    vv[el] = (vv[el] & 0xffff0000u) | 0x3F80u;
+                }
             }
             *reinterpret_cast<u32x4 *>(Ks + k_swz<HDP>(row, ch)) = kv;
             *reinterpret_cast<u32x4 *>(Vs + row * ROWB + ch * 16) = vv;
@@ -260,10 +269,16 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 o = mfma32(__builtin_bit_cast(bf16x8, vv), as_bf16x8(pw), o);
-                lsum = mfma32(as_bf16x8(ones_w), as_bf16x8(pw), lsum);  // every row = sum over this tile's keys, column = query
+                if (!ones_col) lsum = mfma32(as_bf16x8(ones_w), as_bf16x8(pw), lsum);  // every row = sum over this tile's keys, column = query
             }
         }
-        const float inv_l = 1.0f / lsum[0];
+        float l = lsum[0];
+        if (ones_col) {  // row 24 of O^T: register 12 of the lanes with hf == 0; the other half gets it by one exchange
+            const float mine = o[12], other = xhalf(mine);
+            l = hf ? other : mine;
+            if (!hf) o[12] = 0.0f;  // the padding channel itself stays zero in z
+        }
+        const float inv_l = 1.0f / l;
         const int qglob = qt * 32 + r;
         if (qglob < S && item_ok) {
             u16 *dst = a.z + (tok0 + (size_t)qglob * a.pos_stride) * a.zw + head * HDP;

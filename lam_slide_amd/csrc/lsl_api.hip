@@ -632,6 +632,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     aa.HHD = m->HHD;
     aa.zw = m->K2;
     aa.H = d.heads;
+    aa.hd = d.head_dim;
     if (!temporal) {  // sequences (b,t), positions l
         aa.S = L; aa.n_seq = bc * T; aa.inner = 1; aa.outer_stride = L; aa.pos_stride = 1;
     } else {          // sequences (b,l), positions t
