@@ -62,8 +62,8 @@ def flops_per_eval_per_traj(kw, T, L):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="md17_bench", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU per step (0 = workload default)")
     ap.add_argument("--chunk", type=int, default=0, help="trajectories per pass inside the library (0 = default)")
