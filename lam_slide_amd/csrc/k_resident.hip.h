@@ -467,9 +467,11 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
                     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                         for (int nt = 0; nt < NNT; ++nt) acc[t][nt] = mfma16(w1f[t][ks], xf[nt][ks], acc[t][nt]);
+#ifndef RES_LOADS_AFTER_GELU
                     __builtin_amdgcn_sched_barrier(0);
                     if (tt >= 1) load_w(w1n, D, l1_f[(tt + 2) % 5], 4, w1f[(tt + 2) % 5]);
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
                 const float2 *rtab = temporal ? rope_t : rope_l;
                 // mlp: erf-GELU, z columns HHD + (f - 3 HHD)
@@ -489,10 +491,17 @@ __global__ void __launch_bounds__(RES_NTHR, 2) k_resident(ResArgs A) {
                     }
                 }
                 // the last tile's refill and linear2's weight tile: behind the GELU block
+#ifdef RES_LOADS_AFTER_GELU  // conservative build (-DRES_LOADS_AFTER_GELU): every weight load behind the GELU block, ~6 % slower; see the note above
+                __builtin_amdgcn_sched_barrier(0);
+                load_w1(w1n);
+                load_w(B.w2, RES_K2, wave * 16, 12, w2f);
+                __builtin_amdgcn_sched_barrier(0);
+#else
                 __builtin_amdgcn_sched_barrier(0);
                 load_w(w1n, D, l1_f[2], 4, w1f[2]);
                 load_w(B.w2, RES_K2, wave * 16, 12, w2f);
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 // this wave's q (waves 0-3) or k (4-7) head: RMS norm over the head's 32 channels, scale, RoPE (q: * softmax scale * log2 e)
                 const float *sc = pb + (l1_sec == 0 ? RES_P_QS : RES_P_KS);
                 const float post = l1_sec == 0 ? A.q_premul : 1.0f;
