@@ -21,6 +21,10 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // keeping them makes the tools' A/B builds generate the same code as the product.
 #define LSL_PROBE(v, bit) ((v) & (bit))
 
+// counted wait: all but the wave's N youngest vector-memory operations (loads, stores, LDS-DMA count together, in issue order) are done
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // 32x32x16 bf16 MFMA, fp32 accumulate.  Operand maps (lane l: r = l & 31, hf = l >> 5):
 //   A[row r][k = 8 hf + j], B[k = 8 hf + j][col r], j = 0..7
 //   C/D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 hf, reg = 0..15

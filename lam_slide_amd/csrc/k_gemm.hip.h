@@ -31,9 +31,6 @@ struct GemmArgs {
                 // loads, bit1 skip LDS reads + MFMAs, bit2 skip epilogue.  The product library ignores the field.
 };
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 // byte offset of 16-byte chunk `chunk` of row `row` inside a [rows][BK] bf16 stage image (BK = 64 or 32)
 template <int BK>
 __device__ __forceinline__ int swz_bk(int row, int chunk) {
