@@ -41,6 +41,7 @@ struct Lin1Args {
     unsigned div_magic, mod_magic;  // floor(2^32 / d) + 1 (0 when d == 1)
     float inv_hd, q_premul;
     int nt;                         // streaming stores
+    unsigned long long *dbg;        // timing-probe builds only (LIN1_PROBE & 128): per workgroup and wave, 4 cycle sums; else unused
 };
 
 template <int HDP, int K>
@@ -64,10 +65,40 @@ struct Lin1Cfg {
 
 enum { LIN1_QK = 0, LIN1_V = 1, LIN1_MLP = 2 };
 
+// Timing probes for tools/lin1_harness.hip ONLY (compile-time; results wrong when set; the library is built without the macro):
+// 1 no epilogue arithmetic, 2 no MFMAs / fragment reads, 4 no output stores, 8 no weight DMA, 16 no per-block wait + barrier, 32 no activation loads,
+// 64 no fragment reads inside the MFMA chain, 128 cycle stamps per step phase into Lin1Args::dbg
+#ifndef LIN1_PROBE
+#define LIN1_PROBE 0
+#endif
+#ifndef LIN1_PRIO
+#define LIN1_PRIO 0
+#endif
+#ifndef LIN1_PD
+#define LIN1_PD 3  // A fragments requested this many k-steps ahead of their MFMA
+#endif
+
+// erf-GELU of an accumulator value: gelu_fast() (common.hip.h) with max(x, 0) as ONE v_max_f32.  Through the builtins hipcc emits two (a
+// canonicalising v_max x, x first), and the epilogue of an mlp block is bound by its vector-instruction count.  Inline asm is invisible to
+// the hazard recognizer, so this form may only read values that the matrix pipe finished writing long ago: here the accumulator tile of the
+// PREVIOUS block (hundreds of cycles).  Same value as gelu_fast for every non-NaN input.
+__device__ __forceinline__ float lin1_gelu(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    p = fmaf(t, p, 0.5f * 1.421413741f);
+    p = fmaf(t, p, 0.5f * -0.284496736f);
+    p = fmaf(t, p, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * (x * x));
+    float relu;
+    asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(x));
+    return fmaf(-ax, p * t * e, relu);
+}
+
 template <int HDP, int K>
 __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     using C = Lin1Cfg<HDP, K>;
-    constexpr int KS = C::KS, BLK = C::BLK, PPW = C::PPW;
+    constexpr int KS = C::KS, BLK = C::BLK, PPW = C::PPW, ROWB = C::ROWB;
     constexpr int NCO = HDP == 32 ? 8 : 4;  // rotation pairs a lane owns per head
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -83,31 +114,45 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     const long i0 = (U * blockIdx.x / gridDim.x) & ~1L, i1 = blockIdx.x + 1 == gridDim.x ? U : ((U * (blockIdx.x + 1) / gridDim.x) & ~1L);
     if (i0 >= i1) return;  // (uniform)
 
+    // In an 8-wave workgroup the second-dispatched half loses the issue arbitration on every SIMD (priority, then age): measured, waves 4-7
+    // take 30 % longer over a block than their partners, which then wait for them at the barrier.  A static raise of that half only swaps
+    // the roles (measured: waves 0-3 then take 30 % longer): off.
+    if (LIN1_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+
     for (int i = tid * 4; i < g.F; i += 512 * 4) *reinterpret_cast<float4 *>(bias_lds + i) = *reinterpret_cast<const float4 *>(g.bias + i);
 
-    // ---- weight ring: block `blk` -> slot; wave w requests rows w, w + 8, w + 16, w + 24 of a block, one LDS-DMA instruction each ----
+    // ---- weight ring: block -> slot; wave w requests rows 4 w .. 4 w + 3 of a block, one LDS-DMA instruction per row ----
     // The DMA instruction is inline asm ON PURPOSE: behind the builtin, hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of the next LDS
     // access of any kind (it cannot tell the staging image and the bias vector from the ring slot being filled), i.e. it waits for the
     // block it has just requested.  Hidden, the requests stay in flight; their completion is ordered by the counted waits of step_head().
-    // (m0 = LDS destination base; written in the same statement that uses it, the compiler's value restored.  s_nop 4: the base SGPRs
-    // may come straight from a scalar ALU instruction, and nothing pads the 5 wait states of "SALU writes SGPR -> VMEM reads it" inside asm.)
+    // One uniform base per wave and block for both sides; the instruction's immediate offset (i ROWB: added to the global AND the LDS
+    // address) walks the rows, m0 = LDS base + 16 i supplies the pitch padding.  m0 is written in the statement that uses it; s_add_u32
+    // writes SCC, which the statement declares (hipcc keeps ring-slot compares live in SCC across it otherwise: wrong slots, now and then).
     const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))(smem);
     const unsigned lane_src = lane * 16;  // byte offset of the lane's 16-byte chunk in a weight row
-    auto issue = [&](int blk, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int row = wave + 8 * i;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * BLK + row * C::PITCH);
-            const unsigned long long sa = (unsigned long long)(g.W + ((size_t)blk * 32 + row) * K);  // uniform; provably so for the "s" operand:
-            const unsigned long long src = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(sa >> 32)) << 32) |
-                                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)sa);
-            unsigned keep_m0;
-            if (C::LPR == 64 || lane < C::LPR)
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep_m0)
-                             : "v"(lane_src), "s"(src), "s"(dst)
-                             : "memory");
+    const char *const w_rows = reinterpret_cast<const char *>(g.W) + (size_t)(4 * wave) * ROWB;  // row 4 w of block 0
+    auto issue_piece = [&](const char *src, unsigned dst, auto ic) __attribute__((always_inline)) {
+        constexpr int I = decltype(ic)::value;
+        if (LIN1_PROBE & 8) return;
+        const unsigned ls = lane_src;  // (an odr-use: a generic lambda does not capture a variable that only appears as an asm operand)
+        if (C::LPR == 64 || lane < C::LPR) {
+            // (s_nop 4 on the first piece: src / dst may come straight from a scalar ALU instruction and nothing pads the 5 wait states of
+            // "SALU writes SGPR -> VMEM reads it" inside asm; the later pieces read the same registers, long since written)
+            if (I == 0)
+                asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4" ::"v"(ls), "s"(src), "s"(dst), "n"(16 * I), "n"(ROWB * I) : "memory", "scc");
+            else
+                asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4" ::"v"(ls), "s"(src), "s"(dst), "n"(16 * I), "n"(ROWB * I) : "memory", "scc");
         }
+    };
+    auto req_src = [&](int blk) __attribute__((always_inline)) { return w_rows + (size_t)blk * (32 * ROWB); };
+    auto req_dst = [&](int slot) __attribute__((always_inline)) { return lds0 + slot * BLK + 4 * wave * C::PITCH; };
+    auto issue = [&](int blk, int slot) __attribute__((always_inline)) {
+        const char *src = req_src(blk);
+        const unsigned dst = req_dst(slot);
+        issue_piece(src, dst, std::integral_constant<int, 0>());
+        issue_piece(src, dst, std::integral_constant<int, 1>());
+        issue_piece(src, dst, std::integral_constant<int, 2>());
+        issue_piece(src, dst, std::integral_constant<int, 3>());
     };
     const int aoff = r * C::PITCH + 16 * hf;  // A fragment of k-step ks: + 32 ks
 
@@ -141,17 +186,19 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
             a[4 * q4] = b.x; a[4 * q4 + 1] = b.y; a[4 * q4 + 2] = b.z; a[4 * q4 + 3] = b.w;
         }
     };
-    // step head: the block to compute has landed (all but the youngest PPW vector-memory operations of every wave are done: the youngest
-    // are always the DMA of the block after it), every wave has left the previous block -> its slot is free for the block two ahead
-    auto step_head = [&]() __attribute__((always_inline)) {
-        wait_vmcnt<PPW>();
+    // Vector-memory bookkeeping.  A fused step issues, in this order: [the 4 stores of a finished slab: every other step] and the 4 DMA
+    // instructions of the block two ahead, all inside its MFMA chain.  At the head of a step the block to compute must have landed: it
+    // was requested two steps ago, and everything the wave issued after that request is younger: the previous step's stores (if it
+    // flushed a slab) and its 4 DMA instructions.  So s_waitcnt vmcnt(8) (previous step flushed) or vmcnt(4) leaves exactly those in
+    // flight: no head waits for the acknowledgement of a store issued less than a step ago.  Extra younger operations only make a
+    // counted wait conservative, never wrong.  Then the workgroup barrier: every wave's pieces have landed and every wave has left the
+    // previous block, whose slot is free for the block two ahead.
+    auto step_head = [&](auto flushed_c) __attribute__((always_inline)) {
+        if (LIN1_PROBE & 16) return;
+        if (decltype(flushed_c)::value) wait_vmcnt<2 * PPW>();
+        else wait_vmcnt<PPW>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-    };
-    auto request_next = [&]() __attribute__((always_inline)) {
-        issue(dma_blk, dma_slot);  // (past the end of the range: a harmless re-read of the following blocks into a free slot)
-        advance(dma_blk);
-        dma_slot = next_slot(dma_slot);
     };
     // wave-private staging: [32 tokens][64 features] bf16 = 128-byte rows of eight 16-byte chunks, chunk index XOR (row & 7).
     //   write (accumulator layout): lane (token r, half hf), block half ii, feature group q: 8 bytes at r 128 + 16 ((4 ii + q) ^ (r & 7)) + 8 hf
@@ -159,20 +206,29 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     //   read (row-wise): lane (tr = lane >> 3, c = lane & 7), rows row0 + tr, row0 = 0, 8, 16, 24: rd0 + 128 row0 (immediates)
     const unsigned wr0 = (unsigned)(size_t)(LDS_PTR(char))(stage) + r * 128 + 8 * hf + ((r & 7) << 4);
     const unsigned rd0 = (unsigned)(size_t)(LDS_PTR(char))(stage) + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
-    // the 64-feature slab that starts at block `b_even` is complete in the staging image: whole 128-byte row segments, 8 token rows per store
-    // (32-bit per-lane offsets against a uniform base: both output buffers are far below 4 GiB per pass)
-    auto flush_slab = [&](int b_even) __attribute__((always_inline)) {
-        const int fs = b_even * 32;
-        const bool to_qkv = fs < 3 * g.HHD;  // (uniform: sections start on multiples of 64 features)
-        const unsigned stride_b = 2u * (to_qkv ? 3 * g.HHD : g.HHD + g.M);
-        const char *base = reinterpret_cast<const char *>(to_qkv ? g.qkv + fs : g.z + (fs - 2 * g.HHD)) + (size_t)n_wave * stride_b;
-        const unsigned voff = (lane >> 3) * stride_b + 16 * (lane & 7);
-        u32x4 pk[4];
+    // A finished 64-feature slab (blocks b_even, b_even + 1) leaves the staging image as whole 128-byte row segments, 8 token rows per store
+    // instruction (32-bit per-lane offsets against a uniform base: both output buffers are far below 4 GiB per pass); two halves of 2
+    // instructions each, so that a fused step can place them inside its MFMA chain.  Per segment: the wave's first row in both buffers.
+    const char *row_q = nullptr, *row_z = nullptr;
+    const unsigned stride_q = 2u * 3 * g.HHD, stride_z = 2u * (g.HHD + g.M);
+    const unsigned voff_q = (lane >> 3) * stride_q + 16 * (lane & 7), voff_z = (lane >> 3) * stride_z + 16 * (lane & 7);
+    const int slab_z = 3 * (g.HHD >> 5);  // first block that goes to z (uniform; sections start on multiples of 64 features)
+    const char *fl_base = nullptr;
+    unsigned fl_stride8 = 0, fl_voff = 0;
+    auto flush_setup = [&](int b_even) __attribute__((always_inline)) {
+        const bool to_qkv = b_even < slab_z;
+        fl_base = (to_qkv ? row_q : row_z) + 64 * b_even;
+        fl_stride8 = 8 * (to_qkv ? stride_q : stride_z);
+        fl_voff = to_qkv ? voff_q : voff_z;
+    };
+    auto flush_read = [&](int half, u32x4 (&pk)[2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pk[i] = *reinterpret_cast<const LDS_PTR(u32x4)>(rd0 + 1024 * i);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff + 8 * i * stride_b), "v"(pk[i]), "s"(base) : "memory");
+        for (int i = 0; i < 2; ++i) pk[i] = *reinterpret_cast<const LDS_PTR(u32x4)>(rd0 + 1024 * (2 * half + i));
+    };
+    auto flush_store = [&](int half, const u32x4 (&pk)[2]) __attribute__((always_inline)) {
+        if (LIN1_PROBE & 4) return;
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(fl_voff + (2 * half) * fl_stride8), "v"(pk[0]), "s"(fl_base) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(fl_voff + (2 * half + 1) * fl_stride8), "v"(pk[1]), "s"(fl_base) : "memory");
     };
     auto put_group = [&](int ii, int q, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
         const u32x2 pk = {pack2(v0, v1), pack2(v2, v3)};
@@ -230,21 +286,21 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
                 put_group(ii, q, o[0], o[1], o[2], o[3]);
             }
         } else if constexpr (SEC == LIN1_MLP) {
-            const float g0 = gelu_fast(a[2 * s]), g1 = gelu_fast(a[2 * s + 1]);
+            const float g0 = lin1_gelu(a[2 * s]), g1 = lin1_gelu(a[2 * s + 1]);
             if (s & 1) put_group(ii, s >> 1, c0, c1, g0, g1);
             else { c0 = g0; c1 = g1; }
         } else {
             if (s < 4) put_group(ii, s, a[4 * s], a[4 * s + 1], a[4 * s + 2], a[4 * s + 3]);
         }
     };
-    // One step = [head] + 8 slices, each = K / 128 MFMAs of the block being computed (DO_MFMA, into acc[1 - PAR]) + one slice of the epilogue
-    // of the previous block (DO_EPI, from acc[PAR], section SEC), with a scheduling fence between slices: the epilogue's vector instructions
-    // issue in the shadows of the MFMAs of the same wave (and of its SIMD partner), and no more than one slice's temporaries are live.
-    // A fragments are requested PD k-steps ahead of the MFMA that takes them.
-    auto step = [&](auto sec_c, auto par_c, auto mfma_c, auto epi_c) __attribute__((always_inline)) {
+    // One step = 8 slices, each = K / 128 MFMAs of the block being computed (DO_MFMA, into acc[1 - PAR]) + one slice of the epilogue of the
+    // previous block (DO_EPI, from acc[PAR], section SEC) + one side job (a pair of slab stores, one DMA instruction), with a scheduling
+    // fence between slices: everything that is not an MFMA issues in the shadows of the MFMAs of the same wave (and of its SIMD partner),
+    // and no more than one slice's temporaries are live.  A fragments are requested PD k-steps ahead of the MFMA that takes them.
+    auto step = [&](auto sec_c, auto par_c, auto mfma_c, auto epi_c, auto side) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
-        constexpr bool DO_MFMA = decltype(mfma_c)::value != 0, DO_EPI = decltype(epi_c)::value != 0;
-        constexpr int MPS = KS / 8, PD = 3;
+        constexpr bool DO_MFMA = decltype(mfma_c)::value != 0 && !(LIN1_PROBE & 2), DO_EPI = decltype(epi_c)::value != 0;
+        constexpr int MPS = KS / 8, PD = LIN1_PD, MH = (MPS + 1) / 2;
         f32x16 &ac = PAR ? acc0 : acc1;
         const f32x16 &ae = PAR ? acc1 : acc0;
         const char *sb = smem + slot_c * BLK + aoff;
@@ -254,45 +310,95 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
 #pragma unroll
             for (int ks = 0; ks < PD; ++ks) fr[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * ks));
         }
+        side(std::integral_constant<int, -1>());
+#define LIN1_SIDE(S) if (s == S) side(std::integral_constant<int, S>());
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            if (DO_MFMA) {
 #pragma unroll
-                for (int m = 0; m < MPS; ++m) {
+            for (int m = 0; m < MPS; ++m) {
+                if (m == MH) { LIN1_SIDE(0) LIN1_SIDE(1) LIN1_SIDE(2) LIN1_SIDE(3) LIN1_SIDE(4) LIN1_SIDE(5) LIN1_SIDE(6) LIN1_SIDE(7) }
+                if (DO_MFMA) {
                     const int ks = s * MPS + m;
                     ac = mfma32(fr[ks % PD], xreg[ks], ac);
-                    if (ks + PD < KS) fr[ks % PD] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * (ks + PD)));
+                    if (ks + PD < KS && !(LIN1_PROBE & 64)) fr[ks % PD] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * (ks + PD)));
                 }
             }
-            if (DO_EPI) epi_slice(sec_c, s, ae, PAR, c0, c1);
+            if (MH == MPS) { LIN1_SIDE(0) LIN1_SIDE(1) LIN1_SIDE(2) LIN1_SIDE(3) LIN1_SIDE(4) LIN1_SIDE(5) LIN1_SIDE(6) LIN1_SIDE(7) }  // (one MFMA per slice)
+            if (DO_EPI) {
+                if (LIN1_PROBE & 1) epi_slice(std::integral_constant<int, LIN1_V>(), s, ae, PAR, c0, c1);  // (keeps the accumulators live)
+                else epi_slice(sec_c, s, ae, PAR, c0, c1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (DO_MFMA) slot_c = next_slot(slot_c);
+#undef LIN1_SIDE
+        if (decltype(mfma_c)::value != 0) slot_c = next_slot(slot_c);
     };
     std::integral_constant<int, 0> I0;
     std::integral_constant<int, 1> I1;
-    // fused step: MFMAs of block e + 1 beside the epilogue of block e (parity PAR = e & 1, section SEC)
-    auto fused = [&](auto sec_c, auto par_c, int e, bool pending) __attribute__((always_inline)) {
+    auto no_side = [](auto) __attribute__((always_inline)) {};
+    unsigned long long dbg_sum[4] = {0, 0, 0, 0};
+    // fused step: MFMAs of block e + 1 beside the epilogue of block e (parity PAR = e & 1, section SEC).  FLUSH (PAR == 0 steps except the first
+    // of a segment): the slab (e - 2, e - 1) is complete in the staging image and leaves during this step; PREV_FLUSHED: the previous step did
+    auto fused = [&](auto sec_c, auto par_c, auto flush_c, auto prev_c, int e) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
-        step_head();
-        if (PAR == 0 && pending) flush_slab(e - 2);  // stores BEFORE the DMA request: the youngest operations at the next head are the DMA
-        request_next();
+        constexpr bool FLUSH = decltype(flush_c)::value != 0;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        auto stamp = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            return t;
+        };
+        if (LIN1_PROBE & 128) t0 = stamp();
+        step_head(prev_c);
+        if (LIN1_PROBE & 128) t1 = stamp();
+        u32x4 pk[2];
+        if (FLUSH) flush_setup(e - 2);
+        const char *src = req_src(dma_blk);
+        const unsigned dst = req_dst(dma_slot);
         init_acc(PAR ? acc0 : acc1, e + 1);
-        step(sec_c, par_c, I1, I1);
-    };
-    auto run = [&](auto sec_c, int ea, int eb, int b0) __attribute__((always_inline)) {  // fused steps for epilogue blocks [ea, eb) of one section; ea is even
-        int e = ea;
-        for (; e + 1 < eb; e += 2) {
-            fused(sec_c, I0, e, e > b0);
-            fused(sec_c, I1, e + 1, false);
+        if (LIN1_PROBE & 128) t2 = stamp();
+        step(sec_c, par_c, I1, I1, [&](auto sl) __attribute__((always_inline)) {
+            constexpr int SL = decltype(sl)::value;
+            if (FLUSH) {  // slab stores: rows read just ahead of their stores, all of it ahead of this step's first staging write
+                if (SL == -1) flush_read(0, pk);
+                if (SL == 0) {
+                    flush_store(0, pk);
+                    flush_read(1, pk);
+                }
+                if (SL == 1) flush_store(1, pk);
+            }
+            if (SL >= 2 && SL < 2 + PPW) issue_piece(src, dst, std::integral_constant<int, (SL >= 2 && SL < 2 + PPW) ? SL - 2 : 0>());
+        });
+        advance(dma_blk);
+        dma_slot = next_slot(dma_slot);
+        if (LIN1_PROBE & 128) {
+            const unsigned long long t3 = stamp();
+            dbg_sum[0] += t1 - t0; dbg_sum[1] += t2 - t1; dbg_sum[2] += t3 - t2; dbg_sum[3] += 1;
         }
-        if (e < eb) fused(sec_c, I0, e, e > b0);
+    };
+    // fused steps for the epilogue blocks [ea, eb) of one section; every even step flushes (the segment's first fused step is not run here)
+    auto run = [&](auto sec_c, int ea, int eb) __attribute__((always_inline)) {
+        int e = ea;
+        if (e < eb && (e & 1)) {
+            fused(sec_c, I1, I0, I0, e);  // (odd start: the step before it was the segment's first fused step, which does not flush)
+            ++e;
+        }
+        for (; e + 1 < eb; e += 2) {
+            fused(sec_c, I0, I1, I0, e);
+            fused(sec_c, I1, I0, I1, e + 1);
+        }
+        if (e < eb) fused(sec_c, I0, I1, I0, e);
     };
     auto load_co = [&](const float4 *tab, unsigned pos) __attribute__((always_inline)) {
         const float4 *t = tab + (size_t)pos * (HDP / 2) + 2 * hf;
 #pragma unroll
         for (int k = 0; k < NCO; ++k) co[k] = t[4 * (k >> 1) + (k & 1)];
     };
+    std::integral_constant<int, LIN1_QK> SQK;
+    std::integral_constant<int, LIN1_V> SV;
+    std::integral_constant<int, LIN1_MLP> SMLP;
 
     const int qb = g.HHD >> 5;  // blocks per q / k / v section
     long i = i0;
@@ -301,8 +407,10 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         const int tile = (int)(i / NB), b0 = (int)(i % NB);
         const int b1 = (int)((long)NB - b0 < i1 - i ? NB : b0 + (i1 - i));
         n_wave = tile * 256 + wave * 32;
+        row_q = reinterpret_cast<const char *>(g.qkv) + (size_t)n_wave * stride_q;
+        row_z = reinterpret_cast<const char *>(g.z) + (size_t)n_wave * stride_z - 4 * (size_t)g.HHD;  // (z column of feature f: f - 2 HHD)
         // the wave's tokens: B fragments of all k-steps (X is padded to whole tiles)
-        {
+        if (!(LIN1_PROBE & 32) || i == i0) {
             const u16 *xr = g.X + (size_t)(n_wave + r) * K + 8 * hf;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xreg[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + 16 * ks));
@@ -317,50 +425,67 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        request_next();
+        issue(dma_blk, dma_slot);
+        advance(dma_blk);
+        dma_slot = next_slot(dma_slot);
         init_acc(acc0, b0);
-        step(std::integral_constant<int, LIN1_V>(), I1, I1, I0);
-        // fused steps e = b0 .. b1 - 2, split by the section of e
+        step(SV, I1, I1, I0, no_side);
+        // the segment's first fused step (e = b0, even): nothing to flush yet
         const int e_end = b1 - 1;
+        if (b0 < 2 * qb) {
+            load_co(b0 < qb ? g.rope_q : g.rope_k, pos);
+            post = b0 < qb ? g.q_premul : 1.0f;
+            fused(SQK, I0, I0, I0, b0);
+        } else if (b0 < 3 * qb) {
+            fused(SV, I0, I0, I0, b0);
+        } else {
+            fused(SMLP, I0, I0, I0, b0);
+        }
+        // fused steps e = b0 + 1 .. b1 - 2, split by the section of e
         {
-            const int lo = max(b0, 0), hi = min(e_end, qb);
+            const int lo = max(b0 + 1, 0), hi = min(e_end, qb);
+            if (lo < hi) run(SQK, lo, hi);  // (co holds the q table: the segment started inside the q section)
+        }
+        {
+            const int lo = max(b0 + 1, qb), hi = min(e_end, 2 * qb);
             if (lo < hi) {
-                load_co(g.rope_q, pos);
-                post = g.q_premul;
-                run(std::integral_constant<int, LIN1_QK>(), lo, hi, b0);
+                if (lo == qb) {  // entering the k section (otherwise the segment started inside it and co holds the k table)
+                    load_co(g.rope_k, pos);
+                    post = 1.0f;
+                }
+                run(SQK, lo, hi);
             }
         }
         {
-            const int lo = max(b0, qb), hi = min(e_end, 2 * qb);
-            if (lo < hi) {
-                load_co(g.rope_k, pos);
-                post = 1.0f;
-                run(std::integral_constant<int, LIN1_QK>(), lo, hi, b0);
-            }
+            const int lo = max(b0 + 1, 2 * qb), hi = min(e_end, 3 * qb);
+            if (lo < hi) run(SV, lo, hi);
         }
         {
-            const int lo = max(b0, 2 * qb), hi = min(e_end, 3 * qb);
-            if (lo < hi) run(std::integral_constant<int, LIN1_V>(), lo, hi, b0);
-        }
-        {
-            const int lo = max(b0, 3 * qb), hi = min(e_end, NB);
-            if (lo < hi) run(std::integral_constant<int, LIN1_MLP>(), lo, hi, b0);
+            const int lo = max(b0 + 1, 3 * qb), hi = min(e_end, NB);
+            if (lo < hi) run(SMLP, lo, hi);
         }
         // last block of the segment (odd): epilogue only, then its slab
         {
             const int e = b1 - 1;
             if (e < 2 * qb) {
-                load_co(e < qb ? g.rope_q : g.rope_k, pos);
-                post = e < qb ? g.q_premul : 1.0f;
-                step(std::integral_constant<int, LIN1_QK>(), I1, I0, I1);
+                step(SQK, I1, I0, I1, no_side);  // (co is current: e is odd, so its section was entered by an earlier step of this segment)
             } else if (e < 3 * qb) {
-                step(std::integral_constant<int, LIN1_V>(), I1, I0, I1);
+                step(SV, I1, I0, I1, no_side);
             } else {
-                step(std::integral_constant<int, LIN1_MLP>(), I1, I0, I1);
+                step(SMLP, I1, I0, I1, no_side);
             }
-            flush_slab(e - 1);
+            flush_setup(e - 1);
+            u32x4 pk[2];
+            flush_read(0, pk);
+            flush_store(0, pk);
+            flush_read(1, pk);
+            flush_store(1, pk);
         }
         i += b1 - b0;
     }
     wait_vmcnt<0>();  // the ring's run-ahead requests must not land in LDS after the workgroup has gone
+    if ((LIN1_PROBE & 128) && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g.dbg[((size_t)blockIdx.x * 8 + wave) * 4 + k] = dbg_sum[k];
+    }
 }

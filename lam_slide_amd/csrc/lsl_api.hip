@@ -19,6 +19,7 @@
 
 #include "k_attn.hip.h"
 #include "k_gemm.hip.h"
+#include "k_lin1.hip.h"
 #include "k_small.hip.h"
 #include "k_resident.hip.h"
 #ifdef LSL_EXPERIMENTS  // measured-and-rejected GEMM structures, built only by tools/build_experiments.sh (never in the product library)
@@ -127,7 +128,7 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.mods = (float *)take((size_t)bc * m->MODW * 4);
     const size_t n_pad = align_up(n, 256);  // GEMM operand rows: whole 256-token tiles are read without clamping
     ws.a = (u16 *)take(n_pad * D * 2);
-    ws.qkv = (u16 *)take(n * 3 * m->HHD * 2);
+    ws.qkv = (u16 *)take(n_pad * 3 * m->HHD * 2);  // (padded like a / z: the token-stationary linear1 stores whole 256-token tiles)
     ws.z = (u16 *)take(n_pad * m->K2 * 2);
     ws.bytes = off;
     return ws;
@@ -379,6 +380,35 @@ bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
 
 #endif  // LSL_EXPERIMENTS
 
+// linear1 on the token-stationary kernel (k_lin1.hip.h): hidden sizes 128 / 256 / 384 / 512, sections (q | k | v | mlp) on multiples of 64
+// features.  Same bits as the tile kernels below (tools/lin1_harness.hip), so the choice between them may depend on the launch size.
+template <int HDP, int K>
+void launch_linear1_ts_t(const Lin1Args &a, hipStream_t st) {
+    auto kern = k_linear1_ts<HDP, K>;
+    LSL_ALLOW_LDS(kern, (size_t)163840);
+    const long units = (long)((a.N + 255) / 256) * (a.F / 32);
+    const int grid = (int)std::min<long>(device_cus(), units / 2);
+    const size_t lds = Lin1Cfg<HDP, K>::lds_bytes(a.F);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+}
+bool linear1_ts_ok(int hdp, int D, int F1, int HHD, int N) {
+    static const int on = tune_int("LSL_LIN1_TS", 1);
+    if (!on || (hdp != 16 && hdp != 32) || (D != 128 && D != 256 && D != 384 && D != 512) || F1 % 64 != 0 || HHD % 64 != 0 || N < 1) return false;
+    return (size_t)3 * 32 * (2 * D + 16) + 8 * 4096 + (size_t)F1 * 4 <= (size_t)163840;  // weight ring + staging + bias vector (Lin1Cfg::lds_bytes)
+}
+void launch_linear1_ts(int hdp, int D, const Lin1Args &a, hipStream_t st) {
+    switch ((hdp == 32 ? 0 : 4) + D / 128 - 1) {
+        case 0: return launch_linear1_ts_t<32, 128>(a, st);
+        case 1: return launch_linear1_ts_t<32, 256>(a, st);
+        case 2: return launch_linear1_ts_t<32, 384>(a, st);
+        case 3: return launch_linear1_ts_t<32, 512>(a, st);
+        case 4: return launch_linear1_ts_t<16, 128>(a, st);
+        case 5: return launch_linear1_ts_t<16, 256>(a, st);
+        case 6: return launch_linear1_ts_t<16, 384>(a, st);
+        default: return launch_linear1_ts_t<16, 512>(a, st);
+    }
+}
+
 // GEMM tiling (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
 //   (features x tokens, waves, BK x ring stages):
 //   5  256x256  8 waves 64x2, one tile per workgroup
@@ -612,7 +642,12 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     const int pdiv = temporal ? L : 1, pmod = temporal ? T : L;
     auto magic_of = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };
     if ((unsigned long long)n * (unsigned)std::max(pdiv, pmod) >= (1ull << 32)) return fail(-3, "pass too large for the position arithmetic");
-    if (d.head_dim_pad == 32) {
+    if (linear1_ts_ok(d.head_dim_pad, D, m->F1, m->HHD, n)) {
+        const Lin1Args la{(const u16 *)bw.w1, ws.a, bw.b1, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
+                          ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->F1, n, m->HHD, d.mlp_dim,
+                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, nullptr};
+        launch_linear1_ts(d.head_dim_pad, D, la, st);
+    } else if (d.head_dim_pad == 32) {
         EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                          ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->HHD, d.mlp_dim,
                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 0};

@@ -76,7 +76,10 @@ void run_case(int N, int D, int H, int mlp_ratio, int iters, int grid_new, int p
     const int tiles = ((N + 255) / 256) * (Fpad / 256);
     const int grid_old = tiles < 256 ? tiles : 256;
     // ---- new kernel ----
-    Lin1Args la{W, X, b, rq, rk, qkv1, z1, F, N, HHD, M, pdiv, pmod, magic_of(pdiv), magic_of(pmod), inv_hd, premul, 1};
+    unsigned long long *dbg;
+    CK(hipMalloc(&dbg, 256 * 8 * 4 * 8));
+    CK(hipMemset(dbg, 0, 256 * 8 * 4 * 8));
+    Lin1Args la{W, X, b, rq, rk, qkv1, z1, F, N, HHD, M, pdiv, pmod, magic_of(pdiv), magic_of(pmod), inv_hd, premul, 1, dbg};
     auto knew = k_linear1_ts<HDP, K>;
     const size_t lds_new = Lin1Cfg<HDP, K>::lds_bytes(F);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(knew), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -112,6 +115,17 @@ void run_case(int N, int D, int H, int mlp_ratio, int iters, int grid_new, int p
            bad_z ? first_z / (HHD + M) : 0, bad_z ? first_z % (HHD + M) : 0, bad_z ? c0[first_z] : 0, bad_z ? c1[first_z] : 0);
     printf("  %s\n", bad_q + bad_z == 0 ? "BITS EQUAL" : "DIFFERENT");
 
+#if defined(LIN1_PROBE) && (LIN1_PROBE & 128)
+    {
+        std::vector<unsigned long long> hd(256 * 8 * 4);
+        CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+        for (int wg : {0, 1, 100, 255})
+            for (int w : {0, 3, 4, 7}) {
+                const unsigned long long *d = &hd[((size_t)wg * 8 + w) * 4];
+                if (d[3]) printf("  wg %3d wave %d: steps %llu  head %.0f  issue+flush+init %.0f  body %.0f cycles/step\n", wg, w, d[3], (double)d[0] / d[3], (double)d[1] / d[3], (double)d[2] / d[3]);
+            }
+    }
+#endif
     // timing, interleaved rounds
     hipEvent_t ev0, ev1;
     CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
