@@ -49,7 +49,8 @@ typedef struct lsl_model_desc {
 /* One ParallelMLPAttentionV2 (mmdit.py:215-249), packed by lam_slide_amd/packing.py:
  *   w1  bf16 [F1 rounded up to 256][D]   rows = [q heads | k heads | v heads | mlp], each head padded to
  *                      head_dim_pad; zero rows up to a whole 256-row tile (read without clamping)
- *   b1  f32  [F1]      F1 = 3*H*head_dim_pad + M
+ *   b1  f32  [F1 rounded up to 256], zero padded; F1 = 3*H*head_dim_pad + M (the tile kernels copy whole 256-feature tiles of it
+ *                      into LDS: a buffer of exactly F1 floats would be read out of bounds)
  *   qs, ks f32 [head_dim_pad]  QKNorm scales (zero in the padding)
  *   w2  bf16 [D rounded up to 256][K2]   columns = [attention heads (padded) | mlp],  K2 = H*head_dim_pad + M
  *   b2  f32  [D]                                                                         */

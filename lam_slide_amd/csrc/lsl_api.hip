@@ -1014,7 +1014,7 @@ int lsl_debug_res_stamps(unsigned long long *out8) {
 
 int32_t lsl_sampler_path(const lsl_model *m, int32_t T, int32_t L) {
     if (!m || T <= 0 || L <= 0) return -1;
-    return resident_ok(m, T, L) ? 1 : 0;
+    return resident_ok(m, T, L) && m->prof.kernel < 0 ? 1 : 0;  // (per-kernel profiling runs the general kernels: lsl_sample below)
 }
 
 size_t lsl_workspace_bytes(const lsl_model *m, int32_t B, int32_t T, int32_t L) {

@@ -9,6 +9,9 @@ re-exports) to :class:`lam_slide_amd.Sampler`, whose fused loop recognises a ``l
 sampler.  It is idempotent, touches only modules that are ALREADY imported (it never imports the reference itself), and is called
 automatically when a ``lam_slide_amd.LatentSIV3`` or ``lam_slide_amd.CreateTransport`` is constructed, i.e. precisely when one of the
 shipped overrides is active.  ``LSL_NO_INSTALL=1`` disables the automatic call; ``uninstall()`` restores the original names.
+What this package does not implement (torchdiffeq's adaptive ODE solvers: the reference's default ``dopri5``) is delegated to the class
+that was replaced (:func:`original_sampler`) when the call carries the reference's own ``Transport`` object, so other models of the
+same process keep working after the install.
 """
 from __future__ import annotations
 
@@ -51,6 +54,15 @@ def uninstall() -> None:
         if mod is not None:
             setattr(mod, n, orig)
         del _saved[(mod_name, n)]
+
+
+def original_sampler():
+    """The reference's own ``Sampler`` class that :func:`install` replaced (None when nothing is installed): calls this package does not
+    implement (adaptive ODE solvers) are delegated to it."""
+    for (_, n), orig in _saved.items():
+        if n == "Sampler":
+            return orig
+    return None
 
 
 def installed() -> List[str]:

@@ -87,8 +87,10 @@ class SecondStageSampler:
         first_index: global index of ``latents[0]`` when this rank holds rows [first_index, first_index + B) of a sharded batch; the
         streams are indexed by GLOBAL element, so sharded and unsharded runs draw identical noise (every rank must have made the same
         number of calls)."""
-        x_cond, mask = setup_conditioning(latents, self.cond_idx, self.mask_cond_mean)
         call_seed = self._next_call_seed()
+        if latents.shape[0] == 0:  # an empty shard of a sharded run: the call is counted (see sample_sharded), nothing to sample
+            return latents.new_zeros(latents.shape)
+        x_cond, mask = setup_conditioning(latents, self.cond_idx, self.mask_cond_mean)
         elem_offset = int(first_index) * x_cond[0].numel()
         if init is None:
             init = device_randn(x_cond.shape, x_cond.device, call_seed, elem_offset).to(x_cond.dtype)
@@ -155,7 +157,9 @@ def sample_sharded(sample_fn: Callable[[Tensor, int], Tensor], latents: Tensor, 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     B = latents.shape[0]
     lo, hi = shard_bounds(B, world, rank)
-    local = sample_fn(latents[lo:hi], lo) if hi > lo else latents.new_zeros((0,) + tuple(latents.shape[1:]))
+    # (a rank with an empty shard still calls sample_fn: stateful samplers count their calls to key the noise streams, and every rank
+    # has to stay on the same call number as the unsharded run)
+    local = sample_fn(latents[lo:hi], lo)
     sizes = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
     cap = max(sizes)
     pad = local.new_zeros((cap,) + tuple(latents.shape[1:]))

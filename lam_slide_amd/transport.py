@@ -296,6 +296,7 @@ class Sampler:
     same seed."""
 
     def __init__(self, transport: Transport, fused: Optional[bool] = None, keep_trajectory: bool = False, seed: Optional[int] = None):
+        self._given_transport = transport  # (as passed: the reference's Transport object when installed into a reference checkout)
         self.transport = as_transport(transport)
         self.fused = fused
         self.keep_trajectory = keep_trajectory
@@ -306,11 +307,13 @@ class Sampler:
         self.last_kernels: Optional[str] = None  # "general" | "resident" (lsl_sampler_path) after a fused call
         self.elem_offset = 0  # global element index of this rank's first state element (device noise stream)
 
-    def next_call_seed(self) -> int:
+    def next_call_seed(self, draw: bool = True) -> int:
+        """Seed of this call's device-noise stream.  The call counter advances on every call (ranks of a sharded run stay in step even
+        when one of them has an empty shard); the global generator is consumed only when ``draw`` (the call really uses device noise)."""
         k = self.calls
         self.calls += 1
         if self.seed is None:
-            return int(torch.randint(0, 1 << 62, (1,)).item())
+            return int(torch.randint(0, 1 << 62, (1,)).item()) if draw else 0
         return mix_seed(self.seed, k)
 
     # ---- step tables ------------------------------------------------------------------------------------
@@ -383,8 +386,11 @@ class Sampler:
         for name, ten in model_kwargs.items():
             if ten is not None and ten.device != dev:
                 raise RuntimeError(f"Expected all tensors to be on the same device, but {name} is on {ten.device} and the state is on {dev}")
-        call_seed = self.next_call_seed()
-        self.last_seed = call_seed
+        # The call's noise-stream seed is drawn only when the call uses device noise (an Euler-Maruyama step without an explicit noise
+        # tensor).  ODE calls and SDE calls with stored noise leave torch's global generator untouched, like the reference.
+        needs_device_noise = noise is None and any(s[3] != 0.0 for s in steps)
+        call_seed = self.next_call_seed(draw=needs_device_noise)
+        self.last_seed = call_seed if needs_device_noise else None
         with torch.cuda.device(dev):
             net.ensure_packed(dev)
             # the state is updated in place by the library: always a private copy (persistent buffers only under LSL_GRAPH, see staged())
@@ -448,6 +454,14 @@ class Sampler:
     # ---- reference API --------------------------------------------------------------------------------------
     def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False):
         if sampling_method != "euler":
+            # Adaptive / other torchdiffeq solvers (the reference's own ODE default is dopri5, configs/eval_peptide.yaml uses it): not
+            # implemented here.  When this class stands in for the reference's Sampler (dropin.install) and was given the reference's own
+            # Transport object, hand the call to the class it replaced instead of breaking a flow that worked before the install.
+            from . import dropin
+            orig = dropin.original_sampler()
+            if orig is not None and hasattr(self._given_transport, "get_drift"):
+                return orig(self._given_transport).sample_ode(sampling_method=sampling_method, num_steps=num_steps, atol=atol, rtol=rtol,
+                                                              reverse=reverse)
             raise NotImplementedError(f"ODE solver {sampling_method!r}: only torchdiffeq's fixed-grid 'euler' is implemented "
                                       "(dopri5 / adaptive solvers are out of scope, SURVEY.md 8c)")
         steps, grid = self.ode_steps(num_steps, reverse)

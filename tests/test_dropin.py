@@ -69,6 +69,20 @@ def test_install_rebinds_the_module_level_sampler_without_source_edits():
         def __init__(self, transport):
             self.transport = transport
 
+        def sample_ode(self, *, sampling_method, num_steps, atol, rtol, reverse):
+            return ("reference " + sampling_method, self.transport, num_steps)
+
+    class RefTransport:  # the attributes as_transport() reads from a reference Transport (transport.py:36-60) + what marks it as one
+        def __init__(self):
+            import enum
+            self.model_type = enum.Enum("ModelType", "NOISE SCORE VELOCITY DATA").DATA
+            self.path_type = enum.Enum("PathType", "LINEAR GVP VP").GVP
+            self.loss_type = enum.Enum("WeightType", "NONE VELOCITY LIKELIHOOD").NONE
+            self.train_eps = self.sample_eps = 1e-3
+
+        def get_drift(self):
+            return None
+
     fakes = {}
     for name in ("src", "src.modules", "src.modules.transport", "src.modules.transport.transport", "src.models", "src.models.composites",
                  "src.models.composites.lightning_base"):
@@ -90,8 +104,15 @@ def test_install_rebinds_the_module_level_sampler_without_source_edits():
         fn = lb.Sampler(lam_slide_amd.CreateTransport("GVP", "data")()).get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": 3})
         out = fn(torch.zeros(1, 2, 2, 2), lambda x, t, **kw: x)
         assert out.shape == (3, 1, 2, 2, 2)
+        # what this package does not implement (the reference's ODE default, dopri5) goes back to the class that was replaced when the
+        # call carries the reference's own Transport object; with this package's Transport there is nobody to hand it to
+        ref_tr = RefTransport()
+        got = lb.Sampler(ref_tr).get_sample_fn("ODE", {"num_steps": 7})
+        assert got == ("reference dopri5", ref_tr, 7)
+        with pytest.raises(NotImplementedError):
+            lb.Sampler(lam_slide_amd.CreateTransport("GVP", "data")()).get_sample_fn("ODE", {})
         dropin.uninstall()
-        assert lb.Sampler is RefSampler and dropin.installed() == []
+        assert lb.Sampler is RefSampler and dropin.installed() == [] and dropin.original_sampler() is None
     finally:
         dropin.uninstall()
         for k, v in saved.items():
