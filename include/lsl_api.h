@@ -149,6 +149,14 @@ int lsl_randn(float *x, uint64_t n, uint64_t seed, uint64_t elem_offset, void *s
 int lsl_debug_block(lsl_model *m, int32_t block_index /* 0..2*depth-1 */, const float *h_in, float *h_out,
                     const float *mods /* [B, (6*depth+2)*D] */, int32_t B, int32_t T, int32_t L,
                     void *workspace, size_t workspace_bytes, void *stream);
+/* The same sub-block up to and including attention (LayerNorm + modulate, linear1 with its epilogue, attention), then the two
+ * intermediate buffers as the kernels leave them:
+ *   qkv_out bf16 [B*T*L][3 * H * head_dim_pad]  q (after QK-norm and RoPE, times head_dim^-1/2 * log2 e) | k (after QK-norm and RoPE) | v,
+ *                                               head-major inside each third
+ *   z_out   bf16 [B*T*L][H * head_dim_pad + M]  attention output (head-major) | GELU(mlp)
+ * (reference taps: mmdit.py:241-248 q_norm / k_norm / apply_rope / attention / gelu). */
+int lsl_debug_taps(lsl_model *m, int32_t block_index, const float *h_in, const float *mods, int32_t B, int32_t T, int32_t L,
+                   void *qkv_out, void *z_out, void *workspace, size_t workspace_bytes, void *stream);
 int lsl_debug_mods(lsl_model *m, const float *t, const float *y, int32_t B, float *vec_out, float *mods_out,
                    void *workspace, size_t workspace_bytes, void *stream);
 

@@ -19,7 +19,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTED = (
     "lsl_version", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
-    "lsl_model_set_chunk", "lsl_pass_size", "lsl_sampler_path", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_debug_block", "lsl_debug_mods",
+    "lsl_model_set_chunk", "lsl_pass_size", "lsl_sampler_path", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_debug_block", "lsl_debug_taps", "lsl_debug_mods",
     "lsl_profile_enable", "lsl_profile_read", "lsl_randn",
     "lsl_decoder_create", "lsl_decoder_destroy", "lsl_decode_workspace_bytes", "lsl_decode",
     "lsl_encoder_create", "lsl_encoder_destroy", "lsl_encode_workspace_bytes", "lsl_encode",
@@ -122,6 +122,8 @@ def load() -> C.CDLL:
                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_debug_block.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.lsl_debug_taps.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_debug_mods.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]
     lib.lsl_randn.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]

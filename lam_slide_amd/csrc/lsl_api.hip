@@ -624,7 +624,7 @@ void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream
 // a_ready: ws.a already holds this sub-block's LayerNorm + modulate (written by the previous sub-block's linear2); fuse_next: let this
 // sub-block's linear2 write the next one's when the launch allows it (*a_written reports whether it did)
 int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *mods, int mod_stride, int bc, int T, int L,
-              hipStream_t st, bool a_ready = false, bool fuse_next = false, bool *a_written = nullptr) {
+              hipStream_t st, bool a_ready = false, bool fuse_next = false, bool *a_written = nullptr, bool stop_before_linear2 = false) {
     const lsl_model_desc &d = m->d;
     const lsl_block_weights &bw = m->blocks[bi];
     const int D = d.hidden, n = bc * T * L, layer = bi / 2, temporal = bi & 1;
@@ -678,6 +678,10 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     else launch_attention_t<16>(aa, st);
     m->prof.end(2, st);
 
+    if (stop_before_linear2) {  // (lsl_debug_taps)
+        LSL_CHECK_LAUNCH("block");
+        return 0;
+    }
     m->prof.begin(1, st);
     if ((unsigned long long)n * (unsigned)(T * L) >= (1ull << 32)) return fail(-3, "pass too large for the trajectory arithmetic");
     const bool fuse = fuse_next && bi + 1 < 2 * d.depth && linear2_can_fuse_ln(D, n, m->K2);
@@ -1232,6 +1236,30 @@ int lsl_debug_block(lsl_model *m, int32_t bi, const float *h_in, float *h_out, c
     const size_t bytes = (size_t)B * T * L * m->d.hidden * 4;
     if (h_in != h_out) hipMemcpyAsync(h_out, h_in, bytes, hipMemcpyDeviceToDevice, st);
     return run_block(m, ws, bi, h_out, mods, m->MODW, B, T, L, st);
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
+}
+
+int lsl_debug_taps(lsl_model *m, int32_t bi, const float *h_in, const float *mods, int32_t B, int32_t T, int32_t L, void *qkv_out,
+                   void *z_out, void *workspace, size_t workspace_bytes, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
+    if (!m || !m->has_weights) return fail(-2, "weights not set");
+    if (bi < 0 || bi >= 2 * m->d.depth) return fail(-3, "block index out of range");
+    if (!h_in || !mods || !qkv_out || !z_out || B <= 0 || T <= 0 || L <= 0) return fail(-3, "invalid arguments");
+    const size_t need = carve(m, nullptr, B, T, L).bytes;
+    if (!workspace || workspace_bytes < need) return fail(-4, "workspace too small: need %zu bytes", need);
+    hipStream_t st = (hipStream_t)stream;
+    const Workspace ws = carve(m, (char *)workspace, B, T, L);
+    run_tables(m, ws, T, L, st);
+    const size_t n = (size_t)B * T * L;
+    hipMemcpyAsync(ws.h, h_in, n * m->d.hidden * 4, hipMemcpyDeviceToDevice, st);
+    if (int rc = run_block(m, ws, bi, ws.h, mods, m->MODW, B, T, L, st, false, false, nullptr, true)) return rc;
+    hipMemcpyAsync(qkv_out, ws.qkv, n * 3 * m->HHD * 2, hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(z_out, ws.z, n * m->K2 * 2, hipMemcpyDeviceToDevice, st);
+    LSL_CHECK_LAUNCH("debug taps");
+    return 0;
 } catch (const std::bad_alloc &) {
     return fail(-5, "out of host memory");
 } catch (...) {

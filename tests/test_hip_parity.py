@@ -497,3 +497,110 @@ def test_graph_replay_matches_eager_bits(dev):
         os.remove(path)
     assert torch.equal(res["0"], res["2"])
     assert not torch.equal(res["0"][0], res["0"][1])
+
+
+def _hip_taps(net, lib, bi, h_in, mods, B, T, L, dev):
+    """qkv / z of sub-block bi as the kernels leave them (lsl_debug_taps), as float tensors [n, 3, H, hdp] and [n, HHD + M]."""
+    from lam_slide_amd import _lib
+    dm = net.dims
+    n = B * T * L
+    qkv = torch.empty(n, 3 * dm.hhd, dtype=torch.bfloat16, device=dev)
+    z = torch.empty(n, dm.hhd + dm.mlp_dim_pad, dtype=torch.bfloat16, device=dev)
+    ws = torch.empty(int(lib.lsl_workspace_bytes(net._handle, B, T, L)) + (1 << 20), dtype=torch.uint8, device=dev)
+    _lib.check(lib.lsl_debug_taps(net._handle, bi, h_in.data_ptr(), mods.data_ptr(), B, T, L, qkv.data_ptr(), z.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return qkv.float().cpu().reshape(n, 3, dm.heads, dm.head_dim_pad), z.float().cpu()
+
+
+def _check_stage_taps(name, net, lib, sh, taps, h_states, mods, B, T, L, dev, bars):
+    """Every stage between the GEMMs against the reference's (or the oracle's) own intermediates (per-kernel parity):
+    q / k after QK-norm + RoPE, v, attention output, GELU(mlp).  A compensating error between two stages cannot hide here."""
+    import math
+    from oracle import latent_net
+    D, H, hd = sh.hidden_size, sh.num_heads, sh.head_dim
+    premul = 1.4426950408889634 / math.sqrt(hd)
+    worst = {}
+    for i in range(sh.depth):
+        for bi, tag in ((2 * i, f"l{i}.sp."), (2 * i + 1, f"l{i}.tm.")):
+            qkv, z = _hip_taps(net, lib, bi, h_states[bi].to(dev).contiguous(), mods, B, T, L, dev)
+            temporal = bi & 1
+
+            def tok(x):  # reference layout [G, H, S, hd] -> token-major [n, H, hd]
+                if not temporal:
+                    return x.permute(0, 2, 1, 3).reshape(B * T * L, H, hd)
+                return x.reshape(B, L, H, T, hd).permute(0, 3, 1, 2, 4).reshape(B * T * L, H, hd)
+
+            def tok_rows(x):  # [G, S, F] -> [n, F]
+                if not temporal:
+                    return x.reshape(B * T * L, -1)
+                return x.reshape(B, L, T, -1).permute(0, 2, 1, 3).reshape(B * T * L, -1)
+
+            zt = tok_rows(taps[tag + "z"])
+            want = {
+                "q": tok(taps[tag + "q_rope"]), "k": tok(taps[tag + "k_rope"]), "v": zt[:, 2 * D:3 * D].reshape(-1, H, hd),
+                "attn": tok_rows(taps[tag + "attn"]).reshape(-1, H, hd), "gelu": latent_net.gelu_erf(zt[:, 3 * D:]),
+            }
+            got = {
+                "q": qkv[:, 0, :, :hd] / premul, "k": qkv[:, 1, :, :hd], "v": qkv[:, 2, :, :hd],
+                "attn": z[:, :net.dims.hhd].reshape(-1, H, net.dims.head_dim_pad)[:, :, :hd], "gelu": z[:, net.dims.hhd:net.dims.hhd + net.dims.mlp_dim],
+            }
+            for k in want:
+                e = rel_l2(got[k], want[k])
+                worst[k] = max(worst.get(k, 0.0), e)
+            if net.dims.head_dim_pad > hd:  # padded head columns carry nothing into the attention products
+                assert float(qkv[:, :2, :, hd:].abs().max()) == 0.0
+    for k, e in worst.items():
+        parity(f"{name}.{k}", e, bars[k])
+
+
+def test_stage_taps_against_reference_intermediates(golden, dev):
+    """F1: the reference module's own q_norm / rope / attention / linear1 taps (tools/make_fixtures.py), every sub-block fed the reference's
+    input state (16-wide heads, hidden 64: the tile GEMM kernels)."""
+    from lam_slide_amd import _lib
+    from oracle import latent_net
+    f = golden("f1_block.npz")
+    sh = shape_from(f.group("shape"))
+    net = build_net(sh, f.group("p"), dev)
+    net.ensure_packed(dev)
+    taps = f.group("taps")
+    B, T, L, D = 2, 5, 6, sh.hidden_size
+    o_taps = {}
+    latent_net.forward(f.group("p"), sh, f["x"], f["t"], f["x_cond"], f["mask"], f["y"], taps=o_taps)
+    mods = torch.cat([taps[f"l{i}.mod"] for i in range(sh.depth)] + [taps["final_mod"].reshape(B, 2 * D)], dim=1).to(dev).contiguous()
+    h_states, h_prev = [], o_taps["h0"]
+    for i in range(sh.depth):
+        g1 = taps[f"l{i}.mod"][:, 2 * D:3 * D][:, None, None, :]
+        h_states += [h_prev, h_prev + g1 * taps[f"l{i}.sp.out"].reshape(B, T, L, D)]
+        h_prev = taps[f"l{i}.h"]
+    _check_stage_taps("f1.taps", net, _lib.load(), sh, taps, h_states, mods, B, T, L, dev,
+                      dict(q=1.5e-2, k=1.5e-2, v=1.5e-2, attn=1.5e-2, gelu=1.5e-2))
+
+
+@pytest.mark.parametrize("kw,T,L", [
+    (dict(depth=1, in_dim=16, hidden_size=128, num_heads=4, mlp_ratio=2), 6, 40),                       # 32-wide heads (pedestrian family)
+    (dict(depth=1, in_dim=16, hidden_size=256, num_heads=16, mlp_ratio=4, normalize=True), 20, 8),      # 16-wide heads (NBA family)
+    (dict(depth=1, in_dim=16, hidden_size=384, num_heads=16, mlp_ratio=4), 33, 2),                      # 24 -> 32 padded heads (peptide family)
+    (dict(depth=1, in_dim=32, hidden_size=512, num_heads=16, mlp_ratio=2), 3, 256),                     # the headline model's block
+], ids=["d128", "d256", "d384", "d512"])
+def test_stage_taps_of_the_token_stationary_linear1(kw, T, L, dev):
+    """The same stage-by-stage comparison on the hidden sizes that run the token-stationary linear1 kernel (k_lin1.hip.h), against the
+    pinned oracle's taps; B*T*L is not a multiple of 256 in three of the four shapes (ragged last token tile)."""
+    from lam_slide_amd import _lib
+    from oracle import latent_net
+    sh = latent_net.NetShape(**kw)
+    p = latent_net.random_params(sh, seed=21)
+    net = build_net(sh, p, dev)
+    net.ensure_packed(dev)
+    B, C, D = 2, kw["in_dim"], kw["hidden_size"]
+    g = torch.Generator().manual_seed(3)
+    x, xc = torch.randn(B, T, L, C, generator=g), torch.randn(B, T, L, C, generator=g)
+    mask = (torch.rand(B, T, L, generator=g) > 0.5).long()
+    t = torch.rand(B, generator=g)
+    taps = {}
+    latent_net.forward(p, sh, x, t, xc, mask, None, taps=taps)
+    mods = torch.cat([taps[f"l{i}.mod"] for i in range(sh.depth)] + [taps["final_mod"].reshape(B, 2 * D)], dim=1).to(dev).contiguous()
+    g1 = taps["l0.mod"][:, 2 * D:3 * D][:, None, None, :]
+    h_states = [taps["h0"], taps["h0"] + g1 * taps["l0.sp.out"].reshape(B, T, L, D)]
+    _check_stage_taps(f"taps.{D}", net, _lib.load(), sh, taps, h_states, mods, B, T, L, dev,
+                      dict(q=1.5e-2, k=1.5e-2, v=1.5e-2, attn=1.5e-2, gelu=1.5e-2))
