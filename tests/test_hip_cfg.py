@@ -411,3 +411,75 @@ def test_full_size_shapes_of_cfg4_and_cfg5(name, dev):
     assert s.last_path == "fused" and torch.isfinite(full).all()
     parity(f"full.{name}.sampler", rel_l2(full.cpu(), want_s), 1.4 * bar if T > 100 else bar)
     assert torch.equal(full, torch.cat([run(0, 1), run(1, 2)]))
+
+
+def test_cfg5_nba_full_batch_1024(dev):
+    """BASELINE configs[4] at a full single-GPU batch: NBA model (hidden 256, 16 heads of 16, mlp 1024, class vector), T = 20 x L = 8,
+    B = 1024 trajectories x 50 Euler updates: the multi-hundred-tile regime of the K = 256 linear1 / K = 1280 linear2 kernels.  Three
+    trajectories of the big call are bit-equal to the same trajectories sampled alone, two are compared with the oracle."""
+    from lam_slide_amd import CreateTransport, Sampler
+    from oracle import harness, transport as otr
+    kw = dict(depth=6, in_dim=32, hidden_size=256, num_heads=16, mlp_ratio=4, vec_in_dim=256, normalize=True)
+    net, sh, p = _net(kw, 13, dev)
+    B, T, L, C, V = 1024, 20, 8, 32, 256
+    g = torch.Generator().manual_seed(17)
+    lat, init = torch.randn(B, T, L, C, generator=g), torch.randn(B, T, L, C, generator=g)
+    y = torch.randn(B, V, generator=g)
+    xc, m = harness.setup_conditioning(lat, (0, 5), True)
+    skw = {"sampling_method": "euler", "num_steps": 51}
+    s = Sampler(CreateTransport("GVP", "data")(), fused=True)
+    fn = s.get_sample_fn("ODE", skw)
+
+    def run(idx):
+        return fn(init[idx].to(dev), net.forward, x_cond=xc[idx].to(dev), x_cond_mask=m[idx].to(dev), y=y[idx].to(dev))[-1]
+
+    full = run(slice(0, B))
+    assert s.last_path == "fused" and s.last_kernels == "general" and torch.isfinite(full).all()
+    for i in (0, 511, 1023):
+        assert torch.equal(full[i:i + 1], run(slice(i, i + 1))), f"trajectory {i} depends on the batch it is sampled in"
+    pick = [3, 777]
+    want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init[pick], xc[pick], m[pick], y[pick], "ODE", skw)
+    parity("cfg5.nba_b1024.sampler", rel_l2(full[pick].cpu(), want), 1.5e-3)
+
+
+def test_cfg4_peptide_1000_step_sde_device_noise(dev):
+    """BASELINE configs[3] as stated: tetrapeptide model (hidden 384, 16 heads of 24, mlp 1536, 96 channels), T = 1000 x L = 2, the
+    1000-step Euler-Maruyama sampler with the DEVICE Philox stream (no stored noise: the mode production runs use).  Checked: finite,
+    a rerun with the same seed gives the same bits, two half-batches with their global element offsets give the bits of the whole
+    batch (shard invariance of the network AND of the noise), and the injected noise has the moments of N(0, 2 g dt) at every step
+    (recovered from the kept trajectory against a noise-free replay of single steps)."""
+    from lam_slide_amd import CreateTransport, Sampler
+    from oracle import harness
+    kw = dict(depth=7, in_dim=96, hidden_size=384, num_heads=16, mlp_ratio=4)
+    net, sh, p = _net(kw, 19, dev)
+    B, T, L, C = 2, 1000, 2, 96
+    g = torch.Generator().manual_seed(23)
+    lat, init = torch.randn(B, T, L, C, generator=g), torch.randn(B, T, L, C, generator=g)
+    xc, m = harness.setup_conditioning(lat, (0, 1), True)
+    skw = dict(sampling_method="Euler", diffusion_form="linear", diffusion_norm=1.0, last_step="Mean", last_step_size=0.04, num_steps=1000)
+
+    def run(lo, hi, seed=5, keep=False):
+        s = Sampler(CreateTransport("GVP", "data")(), fused=True, seed=seed, keep_trajectory=keep)
+        s.elem_offset = lo * T * L * C
+        out = s.sample_sde(**skw)(init[lo:hi].to(dev), net.forward, x_cond=xc[lo:hi].to(dev), x_cond_mask=m[lo:hi].to(dev))
+        assert s.last_path == "fused"
+        return out
+
+    full = run(0, B)[-1]
+    assert torch.isfinite(full).all()
+    assert torch.equal(full, run(0, B)[-1]), "same seed, different bits"
+    assert not torch.equal(full, run(0, B, seed=6)[-1]), "the seed does not reach the noise"
+    assert torch.equal(full, torch.cat([run(0, 1)[-1], run(1, 2)[-1]])), "sharded halves differ from the whole batch"
+    # per-step moments of the injected noise: x_{s+1} - (ax x_s + am net(x_s, t_s)) = aw w_s; replay single noise-free steps from the kept
+    # states of a short prefix (every 100th step of the first 900) and compare the residual's mean / variance with N(0, aw^2)
+    s = Sampler(CreateTransport("GVP", "data")(), fused=True, seed=5, keep_trajectory=True)
+    steps, _ = s.sde_steps(diffusion_form="linear", diffusion_norm=1.0, last_step="Mean", last_step_size=0.04, num_steps=1000)
+    traj = s.sample_sde(**skw)(init.to(dev), net.forward, x_cond=xc.to(dev), x_cond_mask=m.to(dev))
+    assert torch.equal(traj[-1], full)
+    for k in range(0, 900, 100):
+        te, ax, am, aw = steps[k + 1]
+        x_s = traj[k]           # state after update k = input of update k + 1
+        tv = torch.full((B,), te, device=dev)
+        mean_next = ax * x_s + am * net(x_s, tv, x_cond=xc.to(dev), x_cond_mask=m.to(dev))
+        w = ((traj[k + 1] - mean_next) / aw).flatten().double().cpu()
+        assert abs(float(w.mean())) < 0.02 and abs(float(w.var()) - 1.0) < 0.03, (k, float(w.mean()), float(w.var()))
