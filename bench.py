@@ -16,8 +16,8 @@ relays rank 0's single JSON line.  Documented weak-scaling lines beside the head
     python bench.py --gpus N --workload nba --batch 1024        (BASELINE configs[4]: 1024 trajectories per GPU, 8192 at N=8)
     python bench.py --gpus N --workload peptide --batch 8       (BASELINE configs[3]: 1000-step SDE, 8 trajectories per GPU)
 
-Extra legs on rank 0 at N=1: ``roofline`` (HIP-event timing of the dominant kernel, the linear1 MFMA GEMM,
-inside the timed region), ``gpu_small_batch`` (the same call at B=1 and B=8), ``stage1`` (device encode / decode
+Extra legs on rank 0 at N=1: ``roofline`` / ``roofline2`` (HIP-event timing of every launch of the dominant kernel, the linear1
+MFMA GEMM, and of linear2, in a separate un-overlapped pass after the timed region), ``gpu_small_batch`` (the same call at B=1 and B=8), ``stage1`` (device encode / decode
 of the batch, the steps either side of the loop) and ``cpu_baseline`` (the CPU oracle restatement timed on the
 host cores: the full solve of one trajectory, which is also this run's parity check, a 1-thread figure and an
 all-core figure with several trajectories in flight).
@@ -240,10 +240,9 @@ def run_rank(args) -> int:
     for _ in range(args.warmup):
         one_step()
     # small-trajectory models run the trajectory-resident kernel (one launch per group of state updates, no per-kernel classes to
-    # bracket): the per-kernel HIP-event profiler would force the general path, so it stays off for them
+    # bracket).  The timed region runs the product path as it ships: no profiler, two lanes for large batches (the library overlaps the
+    # two half-batches on two streams); the per-kernel HIP-event timings of the roofline come from a separate pass afterwards
     resident = (not stub) and lib.lsl_sampler_path(net._handle, T, L) == 1
-    if rank == 0 and not stub and not resident:
-        _lib.check(lib.lsl_profile_enable(net._handle, args.profile_kernel, 4096))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -293,26 +292,43 @@ def run_rank(args) -> int:
         return 0
 
     total_ms, launches = C.c_double(), C.c_int32()
-    if not resident:
-        _lib.check(lib.lsl_profile_read(net._handle, C.byref(total_ms), C.byref(launches)))
+
+    def profiled_pass(kid):
+        """One more sampling call with every launch of kernel class `kid` bracketed by HIP events on its launch stream (the library
+        then keeps all passes on one stream: un-overlapped durations).  -> (summed ms, launches)"""
+        _lib.check(lib.lsl_profile_enable(net._handle, kid, 8192))
+        torch.cuda.synchronize()
+        sample_call()
+        torch.cuda.synchronize()
+        tm, ln = C.c_double(), C.c_int32()
+        _lib.check(lib.lsl_profile_read(net._handle, C.byref(tm), C.byref(ln)))
         lib.lsl_profile_enable(net._handle, -1, 0)
+        return tm.value, ln.value
+
+    if not resident:
+        total_ms.value, launches.value = profiled_pass(args.profile_kernel)
     out["config"]["kernels"] = "trajectory-resident (k_resident)" if resident else "general"
     f_eval = flops_per_eval_per_traj(kw, T, L)
     ws_bytes = lib.lsl_workspace_bytes(net._handle, B, T, L)
     pass_size = lib.lsl_pass_size(net._handle, B, T, L)
     out["config"].update({"trajectories_per_pass": pass_size, "workspace_mib": round(ws_bytes / 2 ** 20, 1)})
     passes = -(-B // pass_size)
-    block_evals = 2 * kw["depth"] * n_evals * args.steps          # launches of each block kernel per pass
+    block_evals = 2 * kw["depth"] * n_evals                       # launches of each block kernel per pass and sampling call
     launches_total = passes * block_evals
     tok_total = B * T * L
     if resident:  # the whole call is (groups of) one kernel: its rate is the whole-path rate
         launches_total = 1
         args.profile_kernel = -2
-    kname, kflops_total = {
-        0: ("k_gemm_glds<EpiLinear1> (linear1 + QK-norm/RoPE/GELU epilogue)", 2.0 * tok_total * D * (3 * D + M) * block_evals),
+    hdp = 16 if D // kw["num_heads"] <= 16 else 32
+    lin1_ts = D in (128, 256, 384, 512) and (kw["num_heads"] * hdp) % 64 == 0 and M % 64 == 0
+    lin1_name = ("k_linear1_ts (token-stationary linear1 + bias/QK-norm/RoPE/GELU epilogue)" if lin1_ts
+                 else "k_gemm_glds<EpiLinear1> (linear1 + QK-norm/RoPE/GELU epilogue)")
+    kinfo = {
+        0: (lin1_name, 2.0 * tok_total * D * (3 * D + M) * block_evals),
         1: ("k_gemm_glds<EpiLinear2> (linear2 + gate/residual epilogue)", 2.0 * tok_total * (D + M) * D * block_evals),
         2: ("k_attention", 4.0 * tok_total * D * (L + T) / 2 * block_evals),
-    }.get(args.profile_kernel, (f"kernel class {args.profile_kernel}", 0.0))
+    }
+    kname, kflops_total = kinfo.get(args.profile_kernel, (f"kernel class {args.profile_kernel}", 0.0))
     if resident:
         kname, kflops_total = "k_resident (all state updates of a trajectory in one workgroup)", float(f_eval) * n_evals * B
         total_ms.value, launches.value = dt / args.steps * 1e3, 1
@@ -322,25 +338,41 @@ def run_rank(args) -> int:
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see profiles/): both operand and
     # output bytes scale with the tokens of a launch (weights are < 1 % of them), so the per-token figure is scaled to this run's
     # tokens per launch.  The newest profiles/r*_traffic.json of this workload is used.
-    traffic = None
-    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
-        try:
-            tj = json.load(open(tf))
-            key = {0: "linear1", 1: "linear2"}.get(args.profile_kernel)
-            if key and tj["workload"] == args.workload:
-                traffic = int(tj[key]["bytes"] / tj["tokens_per_launch"] * min(pass_size, B) * T * L)
-                break
-        except (OSError, KeyError, ValueError):
-            continue
+    def committed_traffic(key):
+        """HBM-side bytes per launch of kernel `key` from the newest committed PMC profile of this workload, scaled to this run's
+        tokens per launch; not measured in this run (PMC counters need rocprofv3): the source file is named beside the number."""
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            try:
+                tj = json.load(open(tf))
+                if key and tj["workload"] == args.workload and key in tj:
+                    return int(tj[key]["bytes"] / tj["tokens_per_launch"] * min(pass_size, B) * T * L), os.path.relpath(tf, ROOT)
+            except (OSError, KeyError, ValueError):
+                continue
+        return None, None
+
+    how = ("separate sampling call after the timed region, per-launch HIP events on the launch stream, all passes on one stream "
+           "(un-overlapped; the timed region itself overlaps two half-batches on two streams)")
+    traffic, traffic_src = committed_traffic({0: "linear1", 1: "linear2"}.get(args.profile_kernel))
+    step_ms = dt / args.steps * 1e3
     out["roofline"] = {
         "bound": "mfma", "kernel": kname, "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-        "frac": (achieved / PEAK_BF16_DENSE_TFLOPS) if achieved else None, "traffic": traffic,
-        "launches_timed": launches.value, "launches_total": launches_total, "avg_launch_ms": avg_ms,
+        "frac": (achieved / PEAK_BF16_DENSE_TFLOPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+        "measured": how if not resident else "whole call (one kernel)",
+        "launches_timed": launches.value, "launches_per_call": launches_total, "avg_launch_ms": avg_ms,
         "flops_per_launch": flops_per_launch, "trajectories_per_pass": pass_size,
-        "kernel_time_share": avg_ms * launches_total * 1e-3 / dt,
+        "kernel_time_share": avg_ms * launches_total / step_ms,
         "whole_path_tflops": value * f_eval * n_evals / 1e12,
         "whole_path_frac": value * f_eval * n_evals / 1e12 / PEAK_BF16_DENSE_TFLOPS,
     }
+    if not resident and args.profile_kernel == 0:  # the second GEMM of the block beside it
+        ms2, ln2 = profiled_pass(1)
+        avg2 = ms2 / max(1, ln2)
+        fl2 = kinfo[1][1] / max(1, launches_total)
+        tr2, tr2_src = committed_traffic("linear2")
+        out["roofline2"] = {"bound": "mfma / hbm", "kernel": kinfo[1][0], "achieved": fl2 / (avg2 * 1e-3) / 1e12 if avg2 > 0 else None,
+                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": fl2 / (avg2 * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS if avg2 > 0 else None,
+                            "traffic": tr2, "traffic_source": tr2_src, "measured": how, "launches_timed": ln2, "avg_launch_ms": avg2,
+                            "flops_per_launch": fl2, "kernel_time_share": avg2 * launches_total / step_ms}
 
     def timed_call(fn_, reps=1):
         fn_()
@@ -417,7 +449,8 @@ def cpu_leg(args, kw, T, L, method, skw, n_evals, init, mk, net, tr, dev):
     run = cpu_oracle_runner(args.workload, (init[:1].cpu(), mk["x_cond"][:1].cpu(), mk["x_cond_mask"][:1].cpu(),
                                             mk["y"][:1].cpu() if "y" in mk else None))
     best, cal = None, {}
-    for c in [c for c in (8, 16, 32, 64, 128) if c <= host_cores] or [host_cores]:
+    usable = usable_cores()  # what this process may run on (affinity mask and cgroup quota): less than os.cpu_count() on a shared box
+    for c in [c for c in (4, 8, 16, 32, 64, 128) if c <= usable] or [usable]:
         th.set_num_threads(c)
         if best is None:
             run(one)  # warm-up (allocator, oneDNN primitives)
@@ -429,7 +462,7 @@ def cpu_leg(args, kw, T, L, method, skw, n_evals, init, mk, net, tr, dev):
         if cal[c] > 20.0:
             break
     th.set_num_threads(best)
-    full = cal[best] / one * n_evals <= 45.0
+    full = cal[best] / one * n_evals <= 60.0
     n_sample = n_evals if full else max(2, min(n_evals, int(round(15.0 * one / cal[best]))))
     tc = time.perf_counter()
     cpu_final = run(n_sample)
@@ -451,11 +484,14 @@ def cpu_leg(args, kw, T, L, method, skw, n_evals, init, mk, net, tr, dev):
         parity = {"latents_rel_l2": harness.rel_l2(hip_final.cpu(), cpu_final), "decoded_coord_rel_l2": harness.rel_l2(pos_hip, pos_cpu),
                   "state_updates": done, "bar": 1e-3,
                   "what": f"trajectory 0, {done} of {n_evals} state updates, HIP sampler + HIP decode vs CPU oracle sampler + oracle decode"}
-    cpu = {"value": 1.0 / (per_update * n_evals), "unit": "trajectories/s", "cores": best, "kind": "port", "host_cores": host_cores,
+    single = {"value": 1.0 / (per_update * n_evals), "unit": "trajectories/s", "cores": best,
+              "sample": f"B=1, {done} of {n_evals} state updates timed ({el:.1f} s) with {best} threads (the best intra-op thread count)"
+                        + ("" if full else f", extrapolated linearly to {n_evals}")}
+    cpu = {"value": single["value"], "unit": "trajectories/s", "cores": best, "kind": "port", "host_cores": host_cores, "usable_cores": usable,
            "calibration_s_per_update": {str(k): round(v / one, 2) for k, v in cal.items()},
-           "sample": f"oracle restatement (pure PyTorch fp32, reference op structure, {one} network evaluation(s) per update), B=1, "
-                     f"{done} of {n_evals} state updates timed ({el:.1f} s) with {best} threads"
-                     + ("" if full else f", extrapolated linearly to {n_evals}"), "parity": parity}
+           "sample": "oracle restatement (pure PyTorch fp32, reference op structure, "
+                     f"{one} network evaluation(s) per update): " + single["sample"],
+           "single_trajectory": single, "parity": parity}
     # 1 thread (scripts/md17/second-stage.sh pins OMP_NUM_THREADS=1): one update, extrapolated (per-update cost is constant)
     th.set_num_threads(1)
     tc = time.perf_counter()
@@ -467,7 +503,6 @@ def cpu_leg(args, kw, T, L, method, skw, n_evals, init, mk, net, tr, dev):
     # all usable cores: several trajectories in flight, one worker process each with a few threads (the calibration above shows the
     # intra-op scaling of these small fp32 ops saturates early).  "Usable" = what this process may run on (affinity mask and cgroup
     # quota), which on a shared box is less than os.cpu_count(); wall time is bounded (workers that overrun are stopped and excluded).
-    usable = usable_cores()
     tpw = min(8, best)
     workers = max(1, min(usable // tpw, 32))
     n_w = one + 3
@@ -490,6 +525,11 @@ def cpu_leg(args, kw, T, L, method, skw, n_evals, init, mk, net, tr, dev):
                             "workers_started": workers, "threads_per_worker": tpw,
                             "sample": f"{len(res)} trajectories in flight (one worker process each), {res[0]['updates']} state updates per worker, "
                                       f"{time.perf_counter() - tc:.1f} s wall incl. start-up, extrapolated linearly to {n_evals}"}
+        # the like-for-like figure against a GPU that is kept full: every usable core busy -> that is `value`
+        cpu.update({"value": agg, "cores": len(res) * tpw,
+                    "sample": "oracle restatement (pure PyTorch fp32, reference op structure, "
+                              f"{one} network evaluation(s) per update): " + cpu["all_cores"]["sample"]
+                              + f"; {usable} usable cores (of {host_cores} on the host)"})
     return cpu
 
 

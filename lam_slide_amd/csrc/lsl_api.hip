@@ -136,10 +136,16 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
 
 int env_int(const char *name, int dflt);
 int tune_int(const char *name, int dflt);
+// Two lanes: the passes of a large batch alternate between the caller's stream and a second one, so that one half-batch's memory-bound
+// kernels (LayerNorm, attention, output head: a quarter of the step) and the tails of its persistent GEMM launches share the chip with
+// the other half's kernels: +1.4 % on the cfg-2 bench (profiles/r03_experiments.txt).  Only when each half still makes full-size
+// launches (>= 64 Ki tokens); results do not depend on it (a trajectory's bits are independent of the batch it is sampled in).
+// LSL_LANES=1 (documented runtime switch) keeps everything on the caller's stream.
 int n_lanes() {
-    static const int l = env_int("LSL_LANES", 1);
+    static const int l = env_int("LSL_LANES", 2);
     return l >= 2 ? 2 : 1;
 }
+int lanes_for(int B, int T, int L) { return n_lanes() == 2 && B >= 2 && (size_t)B * T * L >= (size_t)131072 ? 2 : 1; }
 
 int default_chunk(const lsl_model *m, int B, int T, int L) {
     if (m->chunk > 0) return m->chunk < B ? m->chunk : B;
@@ -153,7 +159,7 @@ int default_chunk(const lsl_model *m, int B, int T, int L) {
     size_t c = (size_t)262144 / ((size_t)T * L ? (size_t)T * L : 1);
     if (c < 1) c = 1;
     if (c > (size_t)B) c = B;
-    if (n_lanes() == 2 && B > 1 && c > (size_t)(B + 1) / 2) c = (B + 1) / 2;  // at least one pass per lane
+    if (lanes_for(B, T, L) == 2 && c > (size_t)(B + 1) / 2) c = (B + 1) / 2;  // at least one pass per lane
     return (int)c;
 }
 
@@ -865,7 +871,7 @@ int check_call(const lsl_model *m, const lsl_io *io, size_t ws_bytes, void *ws, 
     if ((io->y != nullptr) != (m->d.vec_in_dim > 0) && io->y != nullptr) return fail(-3, "y given but the model has no vec_in");
     if ((size_t)io->T * io->L > (1u << 24)) return fail(-3, "T*L too large");
     const int chunk = default_chunk(m, io->B, io->T, io->L);
-    size_t need = carve(m, nullptr, chunk, io->T, io->L).bytes * n_lanes();
+    size_t need = carve(m, nullptr, chunk, io->T, io->L).bytes * lanes_for(io->B, io->T, io->L);
     if (resident_ok(m, io->T, io->L)) need = std::max(need, carve_resident(m, nullptr, io->B, io->T, io->L, m->d.vec_in_dim > 0).bytes);
     if (!ws || ws_bytes < need) return fail(-4, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
     *chunk_out = chunk;
@@ -1023,7 +1029,7 @@ int32_t lsl_sampler_path(const lsl_model *m, int32_t T, int32_t L) {
 
 size_t lsl_workspace_bytes(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
     if (!m || B <= 0 || T <= 0 || L <= 0) return 0;
-    size_t need = carve(m, nullptr, default_chunk(m, B, T, L), T, L).bytes * n_lanes();
+    size_t need = carve(m, nullptr, default_chunk(m, B, T, L), T, L).bytes * lanes_for(B, T, L);
     if (resident_ok(m, T, L)) need = std::max(need, carve_resident(m, nullptr, B, T, L, m->d.vec_in_dim > 0).bytes);
     return need;
 }
@@ -1076,7 +1082,7 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
     const int passes = (io->B + chunk - 1) / chunk;
     const long est_launches = (long)passes * n_steps * (8L * m->d.depth + 6);
     const bool launch_bound = (size_t)chunk * io->T * io->L <= 65536;
-    if (use_graph && (launch_bound || use_graph >= 2) && m->prof.kernel < 0 && n_lanes() == 1 && est_launches <= 4096) {
+    if (use_graph && (launch_bound || use_graph >= 2) && m->prof.kernel < 0 && lanes_for(io->B, io->T, io->L) == 1 && est_launches <= 4096) {
         std::vector<unsigned char> key;
         auto put = [&](const void *p, size_t n) { key.insert(key.end(), (const unsigned char *)p, (const unsigned char *)p + n); };
         put(io, sizeof(*io));
@@ -1151,7 +1157,8 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
 
 static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, uint64_t seed,
                           uint64_t elem_offset, float *trace, void *workspace, int chunk, hipStream_t st) {
-    const int lanes = (n_lanes() == 2 && io->B > chunk) ? 2 : 1;
+    // (per-kernel profiling brackets launches with events on ONE stream: un-overlapped, single lane)
+    const int lanes = (lanes_for(io->B, io->T, io->L) == 2 && io->B > chunk && m->prof.kernel < 0) ? 2 : 1;
     hipStream_t lane_st[2] = {st, st};
     if (lanes == 2) {
         if (!m->lane_stream) {
