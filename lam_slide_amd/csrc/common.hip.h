@@ -78,24 +78,23 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// erf-GELU with erfc from Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32 rounding level):
-//   z = |x| / sqrt 2,  t = 1 / (1 + p z),  erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2)
-//   gelu(x) = x * Phi(x),  Phi(-|x|) = erfc(z) / 2  ->  x < 0: x erfc/2 ;  x >= 0: x - x erfc/2
-// No cancellation on the negative side, one v_rcp + one v_exp per element instead of libm erff.
+// erf-GELU (mmdit.py: nn.GELU() = x Phi(x)), round-3 form:  gelu(x) = max(x, 0) - |x| Phi(-|x|),  Phi(-a) = 2^q(a)  with q a degree-5
+// polynomial fitted to log2 Phi(-a) on a in [0, 9] (minimax-weighted for the error of the PRODUCT a Phi(-a); tools/gelu_fit.py).
+// 5 FMA + ONE transcendental + max + FMA = 8 vector instructions (the Abramowitz-Stegun 7.1.26 erfc form of rounds 1-2: 14 with a
+// reciprocal and an exponential) - the linear1 epilogue of an mlp block is bound by its vector-instruction count.
+//   |gelu - x Phi(x)| <= 7e-7 for every x (fp32 evaluation; 7.1.26: 2e-7), no cancellation on the negative side, and for a > 9 the
+//   negative leading coefficient drives q to -inf: 2^q underflows to 0 and gelu(x) = max(x, 0) exactly.
+#define LSL_GELU_Q(ax)                                                                                                  \
+    fmaf(fmaf(fmaf(fmaf(fmaf(-0.0004733090754598379f, (ax), 0.0070845563896000385f), (ax), -0.051827382296323776f), (ax), \
+                   -0.4599924385547638f), (ax), -1.1507878303527832f), (ax), -1.000037670135498f)
 __device__ __forceinline__ float gelu_fast(float x) {
-    // h = Phi(-|x|) = erfc(z)/2 (coefficients pre-halved);  gelu = max(x, 0) - |x| h  on both sides of 0
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
-    p = fmaf(t, p, 0.5f * 1.421413741f);
-    p = fmaf(t, p, 0.5f * -0.284496736f);
-    p = fmaf(t, p, 0.5f * 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * (x * x));
-    // max(x, 0) as ONE instruction the compiler knows (v_med3_f32 x, 0, +inf): fmaxf() costs a second v_max (input canonicalisation), and
-    // an inline-asm v_max is invisible to the hazard recognizer - placed right behind the MFMA that produces x it read the accumulator
-    // before the matrix pipe had written it (no hardware interlock, no s_nop: wrong and timing-dependent results, found in k_resident)
+    const float h = __builtin_amdgcn_exp2f(LSL_GELU_Q(ax));
+    // max(x, 0) through a builtin the compiler knows (v_med3_f32 x, 0, +inf, which it lowers to v_max pairs): an inline-asm v_max is
+    // invisible to the hazard recognizer - placed right behind the MFMA that produces x it read the accumulator before the matrix pipe
+    // had written it (no hardware interlock, no s_nop: wrong and timing-dependent results, found in k_resident in round 2)
     const float relu = __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
-    return fmaf(-ax, p * t * e, relu);
+    return fmaf(-ax, h, relu);
 }
 
 // Streaming ("nt") stores: the line is written out without staying resident in L2.  The GEMM epilogues write 0.5-1.3 GB per

@@ -84,15 +84,10 @@ enum { LIN1_QK = 0, LIN1_V = 1, LIN1_MLP = 2 };
 // PREVIOUS block (hundreds of cycles).  Same value as gelu_fast for every non-NaN input.
 __device__ __forceinline__ float lin1_gelu(float x) {
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
-    p = fmaf(t, p, 0.5f * 1.421413741f);
-    p = fmaf(t, p, 0.5f * -0.284496736f);
-    p = fmaf(t, p, 0.5f * 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * (x * x));
+    const float h = __builtin_amdgcn_exp2f(LSL_GELU_Q(ax));
     float relu;
     asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(x));
-    return fmaf(-ax, p * t * e, relu);
+    return fmaf(-ax, h, relu);
 }
 
 template <int HDP, int K>
@@ -116,7 +111,10 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
 
     // In an 8-wave workgroup the second-dispatched half loses the issue arbitration on every SIMD (priority, then age): measured, waves 4-7
     // take 30 % longer over a block than their partners, which then wait for them at the barrier.  A static raise of that half only swaps
-    // the roles (measured: waves 0-3 then take 30 % longer): off.
+    // the roles (measured: waves 0-3 then take 30 % longer), alternating the priority slice by slice slows both (+10 %): off.  A 4-wave
+    // form of this kernel (one wave per SIMD, 64 tokens and the whole 512-register file per wave, each weight fragment read once for two
+    // MFMAs) was built and is bit-identical, but as scheduled by hipcc it is 11 % slower at K = 256 and spills at K = 512
+    // (profiles/r03_experiments.txt).
     if (LIN1_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     for (int i = tid * 4; i < g.F; i += 512 * 4) *reinterpret_cast<float4 *>(bias_lds + i) = *reinterpret_cast<const float4 *>(g.bias + i);
