@@ -281,7 +281,9 @@ def run_rank(args) -> int:
         "data": "stub (launcher test, not a measurement)" if stub else "synthetic (seeded random weights and latents)",
         "config": {"workload": args.workload, "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
                    "mlp_ratio": kw["mlp_ratio"], "sampler": method, "state_updates": n_evals, "batch_per_gpu": B,
-                   "global_batch": B * world, "parallelism": f"batch-shard x{world}, 1 all_gather/step"},
+                   "global_batch": B * world, "parallelism": f"batch-shard x{world}, 1 all_gather/step",
+                   # rank r draws the device noise of global elements [r * stride, (r + 1) * stride): the slice of the unsharded stream
+                   "noise_elem_stride_per_rank": B * T * L * kw["in_dim"]},
         "rccl_ranks": rccl_ranks, "collective_backend": args.backend if world > 1 else None, "gather_ms": gather_ms,
     }
     if stub:

@@ -334,3 +334,24 @@ def test_bench_self_launches_its_ranks(tmp_path):
     # the product path refuses gloo / CPU
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--no-cpu"], env=env, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
+
+
+@pytest.mark.parametrize("workload,batch,stride", [("nba", 1024, 1024 * 20 * 8 * 32), ("peptide", 8, 8 * 1000 * 2 * 96)])
+def test_bench_eight_ranks_weak_scaling_lines(workload, batch, stride):
+    """The two documented 8-GPU weak-scaling lines (BASELINE configs[4] / [3]) through the real launcher with 8 stub ranks over gloo: eight
+    processes start, rank 0 prints ONE line with the whole-job batch, eight collective ranks and the per-rank stride of the noise stream.
+    No multi-GPU hardware run was available to the builder: this is what can be checked without one."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                          "--stub-compute", "--workload", workload, "--batch", str(batch), "--no-cpu"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "weak" and out["config"]["workload"] == workload
+    assert out["config"]["batch_per_gpu"] == batch and out["config"]["global_batch"] == 8 * batch
+    assert out["config"]["noise_elem_stride_per_rank"] == stride
+    assert out["gather_ms"] is not None and out["value"] > 0
