@@ -102,6 +102,23 @@ typedef struct lsl_step {
     float ax, am, aw;
 } lsl_step;
 
+/* Extended step record (lsl_sample_ex): x <- ax * x + am * network(x, t) + aw * w + as * saved, where `saved` is a copy of the state
+ * taken by an earlier record of the same call.  Enough for every fixed-grid sampler of the reference that is affine per stage, e.g. the
+ * stochastic Heun step (integrators.py:39-51) = three records:
+ *     noise in, keep a copy :  x <- x + sqrt(2 g dt) w                         (LSL_STEP_NO_NETWORK | LSL_STEP_SAVE)
+ *     predictor             :  x <- (1 + dt a(t)) x + dt b(t) net(x, t)
+ *     corrector             :  x <- (1/2 + dt a(t')/2) x + dt b(t')/2 net(x, t') + saved / 2,   t' = t + dt
+ * (drift(x, t) = a(t) x + b(t) net(x, t); the predictor's dt K1 is x_p - x_hat, so no division is needed). */
+#define LSL_STEP_NO_NETWORK 1 /* no network evaluation: x <- ax * x + aw * w + as * saved (am is ignored) */
+#define LSL_STEP_SAVE 2       /* after the update, copy the state into the call's saved-state buffer */
+typedef struct lsl_step_ex {
+    float t;
+    float ax, am, aw, as;
+    int32_t flags;
+    int32_t noise_index; /* slice of `noise` / device-stream step number used for w; ignored when aw == 0 */
+    int32_t trace_index; /* slice of `trace` that receives the state after this record, or -1 */
+} lsl_step_ex;
+
 int lsl_version(void);
 const char *lsl_last_error(void);
 
@@ -136,6 +153,10 @@ int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspac
  * (Philox4x32-10 keyed by seed, counter = (step, global element index + elem_offset); elem_offset makes
  * sharded runs reproduce the unsharded stream).
  * trace: optional device [n_steps, B*T*L*C] receiving the state after every step, or NULL. */
+int lsl_sample_ex(lsl_model *m, const lsl_io *io, const lsl_step_ex *steps, int32_t n_steps,
+                  const float *noise, int32_t n_noise, uint64_t seed, uint64_t elem_offset, float *trace,
+                  void *workspace, size_t workspace_bytes, void *stream);
+/* The same with plain records: record s uses noise slice / stream step s and writes trace slice s. */
 int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps,
                const float *noise, int32_t n_noise, uint64_t seed, uint64_t elem_offset, float *trace,
                void *workspace, size_t workspace_bytes, void *stream);

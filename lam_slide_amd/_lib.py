@@ -19,7 +19,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTED = (
     "lsl_version", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
-    "lsl_model_set_chunk", "lsl_pass_size", "lsl_sampler_path", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_debug_block", "lsl_debug_taps", "lsl_debug_mods",
+    "lsl_model_set_chunk", "lsl_pass_size", "lsl_sampler_path", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_sample_ex", "lsl_debug_block", "lsl_debug_taps", "lsl_debug_mods",
     "lsl_profile_enable", "lsl_profile_read", "lsl_randn",
     "lsl_decoder_create", "lsl_decoder_destroy", "lsl_decode_workspace_bytes", "lsl_decode",
     "lsl_encoder_create", "lsl_encoder_destroy", "lsl_encode_workspace_bytes", "lsl_encode",
@@ -77,6 +77,14 @@ class Step(C.Structure):
     _fields_ = [("t", C.c_float), ("ax", C.c_float), ("am", C.c_float), ("aw", C.c_float)]
 
 
+class StepEx(C.Structure):  # lsl_step_ex
+    _fields_ = [("t", C.c_float), ("ax", C.c_float), ("am", C.c_float), ("aw", C.c_float), ("as_", C.c_float), ("flags", C.c_int32),
+                ("noise_index", C.c_int32), ("trace_index", C.c_int32)]
+
+
+STEP_NO_NETWORK, STEP_SAVE = 1, 2
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR))] + [os.path.join(INCLUDE_DIR, "lsl_api.h")]
@@ -120,6 +128,8 @@ def load() -> C.CDLL:
     lib.lsl_forward.argtypes = [C.c_void_p, C.POINTER(IO), C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_sample.argtypes = [C.c_void_p, C.POINTER(IO), C.POINTER(Step), C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64,
                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.lsl_sample_ex.argtypes = [C.c_void_p, C.POINTER(IO), C.POINTER(StepEx), C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64,
+                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_debug_block.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_debug_taps.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

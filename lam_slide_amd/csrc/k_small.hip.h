@@ -537,6 +537,21 @@ __global__ void __launch_bounds__(256) k_randn(float *x, unsigned long long n, u
         x[e] = philox_normal(seed, step, elem_offset + e);
 }
 
+// A record of lsl_sample_ex without a network evaluation: x <- ax x + aw w + as saved (the noise injection of a Heun step), optionally
+// copied to the saved-state buffer and to the trace.  Same noise addressing as the output-head kernels.
+__global__ void __launch_bounds__(256) k_state_affine(float *x, unsigned long long n, float ax, float aw, float as, const float *noise,
+                                                      unsigned long long seed, unsigned step, unsigned long long elem_offset, const float *saved,
+                                                      float *save_out, float *trace) {
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * 256) {
+        float xn = ax * x[e];
+        if (aw != 0.0f) xn += aw * (noise ? noise[e] : philox_normal(seed, step, elem_offset + e));
+        if (saved) xn += as * saved[e];
+        x[e] = xn;
+        if (trace) trace[e] = xn;
+        if (save_out) save_out[e] = xn;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Output head fused with the sampler update (latent_si_v31.py:185-187 + the affine step of lsl_step):
 //   m = Linear_{D->C}(LayerNorm_{1e-6}(h) * (1 + scale) + shift)          (fp32 FMA chain, exact fp32 weights)
@@ -554,7 +569,8 @@ __global__ void __launch_bounds__(256) k_head_step(float *x, float *out, const f
                                                    const float *scale, int mod_stride, const float *Wo, const float *bo,
                                                    int N, int C, int tokens_per_traj, int do_step, float ax, float am,
                                                    float aw, const float *noise, unsigned long long seed, unsigned step,
-                                                   unsigned long long elem_offset, float *trace) {
+                                                   unsigned long long elem_offset, float *trace, float as, const float *saved,
+                                                   float *save_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = NE * 64, AS = D + 4, WS = D + 1, RPW = HEAD_TOK / 4;  // rows per wave
     float4 *Ws = reinterpret_cast<float4 *>(smem);                    // [8][WS]
@@ -625,8 +641,10 @@ __global__ void __launch_bounds__(256) k_head_step(float *x, float *out, const f
                         if (do_step) {
                             float xn = ax * x[e] + am * m;
                             if (aw != 0.0f) xn += aw * (noise ? noise[e] : philox_normal(seed, step, elem_offset + e));
+                            if (saved) xn += as * saved[e];  // (lsl_step_ex: a state kept by an earlier record, e.g. Heun's x_hat)
                             x[e] = xn;
                             if (trace) trace[e] = xn;
+                            if (save_out) save_out[e] = xn;
                         } else {
                             out[e] = m;
                         }
@@ -652,7 +670,8 @@ template <int NE, int VEC>
 __global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, const float *h, const float *shift, const float *scale,
                                                         int mod_stride, const float *Wo, const float *bo, int N, int C, int tokens_per_traj,
                                                         int do_step, float ax, float am, float aw, const float *noise, unsigned long long seed,
-                                                        unsigned step, unsigned long long elem_offset, float *trace) {
+                                                        unsigned step, unsigned long long elem_offset, float *trace, float as,
+                                                        const float *saved, float *save_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = NE * 64, AS = D + 4, RPW = HEAD_TOK / 4, KW = D / 4, JS = KW / 8;  // k range per wave, 8-deep steps per wave
     float *As = reinterpret_cast<float *>(smem);  // [HEAD_TOK][AS]  LayerNorm'ed + modulated rows
@@ -726,8 +745,10 @@ __global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, co
                         if (do_step) {
                             float xn = ax * x[e] + am * m;
                             if (aw != 0.0f) xn += aw * (noise ? noise[e] : philox_normal(seed, step, elem_offset + e));
+                            if (saved) xn += as * saved[e];  // (lsl_step_ex: a state kept by an earlier record, e.g. Heun's x_hat)
                             x[e] = xn;
                             if (trace) trace[e] = xn;
+                            if (save_out) save_out[e] = xn;
                         } else {
                             out[e] = m;
                         }

@@ -100,6 +100,7 @@ struct Workspace {
     float4 *rope_qk;        // [2 * depth blocks][q, k][max(T, L) positions][head_dim_pad / 2]: RoPE x QK-norm scales (k_rope_scaled)
     size_t rope_qk_stride;  // float4 elements between consecutive (block, q|k) tables
     float *cond_emb, *h, *yemb, *tfeat, *hid, *vec, *mods;
+    float *saved;  // [n][C] state kept by an LSL_STEP_SAVE record of lsl_sample_ex (Heun's x_hat)
     u16 *a, *qkv, *z;
     size_t bytes;
 };
@@ -126,6 +127,7 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.hid = (float *)take((size_t)bc * D * 4);
     ws.vec = (float *)take((size_t)bc * D * 4);
     ws.mods = (float *)take((size_t)bc * m->MODW * 4);
+    ws.saved = (float *)take(n * d.in_dim * 4);
     const size_t n_pad = align_up(n, 256);  // GEMM operand rows: whole 256-token tiles are read without clamping
     ws.a = (u16 *)take(n_pad * D * 2);
     ws.qkv = (u16 *)take(n_pad * 3 * m->HHD * 2);  // (padded like a / z: the token-stationary linear1 stores whole 256-token tiles)
@@ -228,7 +230,8 @@ int env_int(const char *name, int dflt);
 template <int NE, int VEC>
 void launch_head_t(float *x, float *out, const float *h, const float *shift, const float *scale, int stride, const float *Wo,
                    const float *bo, int n, int C, int tpt, int do_step, float ax, float am, float aw, const float *noise,
-                   unsigned long long seed, unsigned step, unsigned long long eo, float *trace, hipStream_t st) {
+                   unsigned long long seed, unsigned step, unsigned long long eo, float *trace, float as, const float *saved, float *save_out,
+                   hipStream_t st) {
 #ifdef LSL_EXPERIMENTS
     static const int mfma = tune_int("LSL_HEAD_MFMA", 1);  // 0: the scalar-FMA kernel (A/B measurements)
     if (!mfma) {
@@ -236,7 +239,7 @@ void launch_head_t(float *x, float *out, const float *h, const float *shift, con
         constexpr size_t lds = head_lds_bytes<NE>();
         LSL_ALLOW_LDS(kern, lds);
         hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, 256)), dim3(256), lds, st, x, out, h, shift, scale, stride, Wo, bo, n,
-                           C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
+                           C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace, as, saved, save_out);
         return;
     }
 #endif
@@ -244,7 +247,7 @@ void launch_head_t(float *x, float *out, const float *h, const float *shift, con
     constexpr size_t lds = head_mfma_lds_bytes<NE>();
     LSL_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, device_cus())), dim3(256), lds, st, x, out, h, shift, scale, stride,
-                       Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace);
+                       Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace, as, saved, save_out);
 }
 
 #define DISPATCH_D(D, FN, ...)                          \
@@ -704,7 +707,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
 // do_step: fuse the affine update into the head; else write the network output to `out`.
 int run_eval(lsl_model *m, const Workspace &ws, float *x, float *out, const float *t_dev, float t_scalar, bool have_y, int bc,
              int T, int L, int do_step, float ax, float am, float aw, const float *noise, uint64_t seed, unsigned step,
-             uint64_t elem_off, float *trace, hipStream_t st) {
+             uint64_t elem_off, float *trace, hipStream_t st, float as = 0.0f, const float *saved = nullptr, float *save_out = nullptr) {
     const lsl_model_desc &d = m->d;
     const int D = d.hidden, n = bc * T * L;
     // modulation rows: one per trajectory, or a single shared row when t is a scalar and there is no y
@@ -728,7 +731,7 @@ int run_eval(lsl_model *m, const Workspace &ws, float *x, float *out, const floa
     const float *fm = ws.mods + (size_t)d.depth * 6 * D;  // adaLN: shift, scale
     m->prof.begin(4, st);
     DISPATCH_D(D, launch_head_t, x, out, ws.h, fm, fm + D, mod_stride, m->w.out_w, m->w.out_b, n, d.in_dim, T * L, do_step, ax, am, aw,
-               noise, (unsigned long long)seed, step, (unsigned long long)elem_off, trace, st);
+               noise, (unsigned long long)seed, step, (unsigned long long)elem_off, trace, as, saved, save_out, st);
     m->prof.end(4, st);
     LSL_CHECK_LAUNCH("head");
     return 0;
@@ -1058,21 +1061,43 @@ int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspac
     return fail(-11, "unexpected C++ exception");
 }
 
-static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, uint64_t seed,
+static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step_ex *steps, int32_t n_steps, const float *noise, uint64_t seed,
                           uint64_t elem_offset, float *trace, void *workspace, int chunk, hipStream_t st);
 
 int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, int32_t n_noise, uint64_t seed,
                uint64_t elem_offset, float *trace, void *workspace, size_t workspace_bytes, void *stream) try {
+    if (!steps || n_steps <= 0) return fail(-3, "steps required");
+    std::vector<lsl_step_ex> ex((size_t)n_steps);
+    for (int s = 0; s < n_steps; ++s) ex[s] = lsl_step_ex{steps[s].t, steps[s].ax, steps[s].am, steps[s].aw, 0.0f, 0, s, s};
+    return lsl_sample_ex(m, io, ex.data(), n_steps, noise, n_noise, seed, elem_offset, trace, workspace, workspace_bytes, stream);
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
+}
+
+int lsl_sample_ex(lsl_model *m, const lsl_io *io, const lsl_step_ex *steps, int32_t n_steps, const float *noise, int32_t n_noise, uint64_t seed,
+                  uint64_t elem_offset, float *trace, void *workspace, size_t workspace_bytes, void *stream) try {
     DeviceGuard dev_guard_((hipStream_t)stream);
     int chunk = 0;
     if (int rc = check_call(m, io, workspace_bytes, workspace, &chunk)) return rc;
     if (!steps || n_steps <= 0) return fail(-3, "steps required");
-    if (noise)
-        for (int s = n_noise < 0 ? 0 : n_noise; s < n_steps; ++s)
-            if (steps[s].aw != 0.0f) return fail(-3, "step %d needs noise but only %d slices were given", s, n_noise);
+    bool plain = true, have_saved = false;
+    for (int s = 0; s < n_steps; ++s) {
+        const lsl_step_ex &sp = steps[s];
+        if (sp.aw != 0.0f && (sp.noise_index < 0 || (noise && sp.noise_index >= n_noise)))
+            return fail(-3, "step %d needs noise slice %d but only %d slices were given", s, sp.noise_index, n_noise);
+        if (sp.trace_index >= n_steps) return fail(-3, "step %d: trace slice %d out of range", s, sp.trace_index);
+        if (sp.as != 0.0f && !have_saved) return fail(-3, "step %d reads the saved state before any record saved one", s);
+        have_saved |= (sp.flags & LSL_STEP_SAVE) != 0;
+        plain &= sp.as == 0.0f && sp.flags == 0 && sp.noise_index == s && sp.trace_index == s;
+    }
     hipStream_t st = (hipStream_t)stream;
-    if (resident_ok(m, io->T, io->L) && m->prof.kernel < 0)  // small trajectories: the whole loop in one launch per group of updates
-        return resident_sample(m, io, steps, n_steps, noise, seed, elem_offset, trace, workspace, st);
+    if (plain && resident_ok(m, io->T, io->L) && m->prof.kernel < 0) {  // small trajectories: the whole loop in one launch per group of updates
+        std::vector<lsl_step> ps((size_t)n_steps);
+        for (int s = 0; s < n_steps; ++s) ps[s] = lsl_step{steps[s].t, steps[s].ax, steps[s].am, steps[s].aw};
+        return resident_sample(m, io, ps.data(), n_steps, noise, seed, elem_offset, trace, workspace, st);
+    }
     // hipGraph replay (opt-in).  LSL_GRAPH: 0 off (default), 1 for launch-bound calls (at most 64 Ki tokens per pass and 4096 launches) whose
     // arguments repeat, 2 for every call of at most 4096 launches: the first appearance of an argument set runs eagerly (it also initialises
     // the per-kernel attributes), the second is captured, later ones are replayed.  Measured on MI355X (tools/latency_small_batch.py): a
@@ -1086,7 +1111,7 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
         std::vector<unsigned char> key;
         auto put = [&](const void *p, size_t n) { key.insert(key.end(), (const unsigned char *)p, (const unsigned char *)p + n); };
         put(io, sizeof(*io));
-        put(steps, sizeof(lsl_step) * n_steps);
+        put(steps, sizeof(lsl_step_ex) * n_steps);
         put(&noise, sizeof(noise));
         put(&seed, sizeof(seed));
         put(&elem_offset, sizeof(elem_offset));
@@ -1155,7 +1180,7 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
     return fail(-11, "unexpected C++ exception");
 }
 
-static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps, const float *noise, uint64_t seed,
+static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step_ex *steps, int32_t n_steps, const float *noise, uint64_t seed,
                           uint64_t elem_offset, float *trace, void *workspace, int chunk, hipStream_t st) {
     // (per-kernel profiling brackets launches with events on ONE stream: un-overlapped, single lane)
     const int lanes = (lanes_for(io->B, io->T, io->L) == 2 && io->B > chunk && m->prof.kernel < 0) ? 2 : 1;
@@ -1195,14 +1220,24 @@ static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step *steps,
                 return rc;
         }
         for (int s = 0; s < n_steps; ++s) {
-            const lsl_step &sp = steps[s];
+            const lsl_step_ex &sp = steps[s];
             for (int l = 0; l < nl; ++l) {
                 const int b0 = b0s[l];
                 const float *nz = nullptr;
-                if (sp.aw != 0.0f && noise) nz = noise + (size_t)s * total + b0 * per;
-                float *tr = trace ? trace + (size_t)s * total + b0 * per : nullptr;
+                if (sp.aw != 0.0f && noise) nz = noise + (size_t)sp.noise_index * total + b0 * per;
+                float *tr = trace && sp.trace_index >= 0 ? trace + (size_t)sp.trace_index * total + b0 * per : nullptr;
+                const float *saved = sp.as != 0.0f ? wss[l].saved : nullptr;        // (the pass's own copy: passes run all records for their trajectories)
+                float *save_out = (sp.flags & LSL_STEP_SAVE) ? wss[l].saved : nullptr;
+                if (sp.flags & LSL_STEP_NO_NETWORK) {
+                    const unsigned long long ne = (unsigned long long)bcs[l] * per;
+                    hipLaunchKernelGGL(k_state_affine, dim3((unsigned)std::min<unsigned long long>((ne + 255) / 256, 2048)), dim3(256), 0, lane_st[l],
+                                       io->x + b0 * per, ne, sp.ax, sp.aw, sp.as, nz, (unsigned long long)seed, (unsigned)sp.noise_index,
+                                       (unsigned long long)(elem_offset + b0 * per), saved, save_out, tr);
+                    LSL_CHECK_LAUNCH("state update");
+                    continue;
+                }
                 if (int rc = run_eval(m, wss[l], io->x + b0 * per, nullptr, nullptr, sp.t, io->y != nullptr, bcs[l], io->T, io->L, 1, sp.ax, sp.am, sp.aw,
-                                      nz, seed, (unsigned)s, elem_offset + b0 * per, tr, lane_st[l]))
+                                      nz, seed, (unsigned)sp.noise_index, elem_offset + b0 * per, tr, lane_st[l], sp.as, saved, save_out))
                     return rc;
             }
         }

@@ -371,9 +371,43 @@ class Sampler:
             raise NotImplementedError()
         return steps, grid
 
+    def heun_records(self, *, diffusion_form, diffusion_norm, last_step, last_step_size, num_steps):
+        """Extended step records (``lsl_step_ex``: t, ax, am, aw, as, flags, noise slice, trace slice) of the stochastic Heun sampler
+        (integrators.py:39-51) followed by the reference's last step.  drift(x, t) = a(t) x + b(t) net(x, t), so per step
+            x_hat = x + sqrt(2 g(t) dt) w                       no network, state kept
+            x_p   = (1 + dt a(t)) x_hat + dt b(t) net(x_hat, t)
+            x'    = x_hat + dt/2 (K1 + K2) = x_hat / 2 + (1/2 + dt a(t')/2) x_p + dt b(t')/2 net(x_p, t'),   t' = t + dt
+        (dt K1 = x_p - x_hat).  Returned with the EM table's last step appended (same last-step rule as Euler-Maruyama)."""
+        em, grid = self.sde_steps(diffusion_form=diffusion_form, diffusion_norm=diffusion_norm, last_step=last_step,
+                                  last_step_size=last_step_size, num_steps=num_steps)
+        tr, sch = self.transport, self.transport.schedule
+        dt = float(grid[1] - grid[0])
+
+        def drift(t):
+            vx, vm = tr.velocity_coeffs(t)
+            sx, sm = tr.score_coeffs(t)
+            g = sch.diffusion(t, diffusion_form, diffusion_norm)
+            return vx + g * sx, vm + g * sm, g
+
+        rec = []
+        for i in range(num_steps - 1):
+            ti = float(grid[i])
+            tn = _f32(_f32(ti) + _f32(dt))  # t_cur + dt in fp32, as the reference forms it
+            dx, dm, g = drift(ti)
+            dx2, dm2, _ = drift(tn)
+            rec.append((ti, 1.0, 0.0, math.sqrt(2 * g) * math.sqrt(dt), 0.0, _lib.STEP_NO_NETWORK | _lib.STEP_SAVE, i, -1))
+            rec.append((ti, 1.0 + dt * dx, dt * dm, 0.0, 0.0, 0, 0, -1))
+            rec.append((tn, 0.5 + 0.5 * dt * dx2, 0.5 * dt * dm2, 0.0, 0.5, 0, 0, i))
+        if len(em) == num_steps:  # the last step (Mean / Euler / Tweedie)
+            te, ax, am, _ = em[-1]
+            rec.append((te, ax, am, 0.0, 0.0, 0, 0, num_steps - 1))
+        return rec, grid
+
     # ---- fused execution ----------------------------------------------------------------------------------
     def run_fused(self, net: LatentSIV3, init: Tensor, steps, n_result: int, model_kwargs: Dict[str, Any],
-                  noise: Optional[Tensor] = None, duplicate_last: bool = False) -> SampleResult:
+                  noise: Optional[Tensor] = None, duplicate_last: bool = False, records=None) -> SampleResult:
+        """``steps``: plain (t, ax, am, aw) records -> lsl_sample; ``records``: extended ones (heun_records) -> lsl_sample_ex, with
+        ``steps`` then only giving the number of kept states."""
         extra = set(model_kwargs) - {"x_cond", "x_cond_mask", "y"}
         if extra:
             raise TypeError(f"unexpected model kwargs {sorted(extra)}")
@@ -388,7 +422,8 @@ class Sampler:
                 raise RuntimeError(f"Expected all tensors to be on the same device, but {name} is on {ten.device} and the state is on {dev}")
         # The call's noise-stream seed is drawn only when the call uses device noise (an Euler-Maruyama step without an explicit noise
         # tensor).  ODE calls and SDE calls with stored noise leave torch's global generator untouched, like the reference.
-        needs_device_noise = noise is None and any(s[3] != 0.0 for s in steps)
+        table = records if records is not None else steps
+        needs_device_noise = noise is None and any(s[3] != 0.0 for s in table)
         call_seed = self.next_call_seed(draw=needs_device_noise)
         self.last_seed = call_seed if needs_device_noise else None
         with torch.cuda.device(dev):
@@ -402,23 +437,31 @@ class Sampler:
                 yv = net.staged("y", yv, torch.float32, dev)
             io, keep = net.make_io(x, xc, xm, yv)
             ws = net.workspace(io.B, io.T, io.L, dev)
-            arr = (_lib.Step * len(steps))(*[_lib.Step(*s) for s in steps])
+            if records is None:
+                arr = (_lib.Step * len(steps))(*[_lib.Step(*s) for s in steps])
+            else:
+                arr = (_lib.StepEx * len(records))(*[_lib.StepEx(*r) for r in records])
             trace = None
             if self.keep_trajectory:
                 trace = torch.empty((len(steps),) + tuple(x.shape), dtype=torch.float32, device=dev)
             nz = None
-            if noise is not None:  # slice s belongs to step s, like the reference's one draw per EM step
+            if noise is not None:  # slice s belongs to step s, like the reference's one draw per EM / Heun step
                 nz = noise.detach().float().contiguous().to(dev)
-                need = max([i + 1 for i, s in enumerate(steps) if s[3] != 0.0], default=0)
+                if records is None:
+                    need = max([i + 1 for i, s in enumerate(steps) if s[3] != 0.0], default=0)
+                else:
+                    need = max([r[6] + 1 for r in records if r[3] != 0.0], default=0)
                 if nz.shape[0] < need or tuple(nz.shape[1:]) != tuple(x.shape):
                     raise ValueError(f"noise must be [>={need}, {tuple(x.shape)}], got {tuple(nz.shape)}")
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(lib.lsl_sample(net._handle, C.byref(io), arr, len(steps), nz.data_ptr() if nz is not None else None,
-                                      nz.shape[0] if nz is not None else 0, call_seed, self.elem_offset,
-                                      trace.data_ptr() if trace is not None else None, ws.data_ptr(), ws.numel(), stream))
+            fn_ = lib.lsl_sample if records is None else lib.lsl_sample_ex
+            _lib.check(fn_(net._handle, C.byref(io), arr, len(arr), nz.data_ptr() if nz is not None else None,
+                           nz.shape[0] if nz is not None else 0, call_seed, self.elem_offset,
+                           trace.data_ptr() if trace is not None else None, ws.data_ptr(), ws.numel(), stream))
         net.last_path = "hip"
         self.last_path = "fused"
-        self.last_kernels = "resident" if lib.lsl_sampler_path(net._handle, io.T, io.L) == 1 else "general"
+        # (extended records always run the general kernels: the trajectory-resident kernel implements the plain affine step only)
+        self.last_kernels = "resident" if records is None and lib.lsl_sampler_path(net._handle, io.T, io.L) == 1 else "general"
         del keep
         if net.graph_replay_enabled():
             x = x.clone()  # the persistent buffer is overwritten by the next call
@@ -493,11 +536,16 @@ class Sampler:
         steps, grid = self.sde_steps(diffusion_form=diffusion_form, diffusion_norm=diffusion_norm, last_step=last_step,
                                      last_step_size=last_step_size, num_steps=num_steps)
         dt = grid[1] - grid[0]
+        records = None
+        if sampling_method == "Heun":
+            records, _ = self.heun_records(diffusion_form=diffusion_form, diffusion_norm=diffusion_norm, last_step=last_step,
+                                           last_step_size=last_step_size, num_steps=num_steps)
 
         def _sample(init, model, **model_kwargs):
             net = resolve_backbone(model) if self.fused is not False else None
-            if net is not None and init.is_cuda and sampling_method == "Euler":
-                return self.run_fused(net, init, steps, num_steps, model_kwargs, noise=noise, duplicate_last=last_step is None)
+            if net is not None and init.is_cuda:
+                return self.run_fused(net, init, steps, num_steps, model_kwargs, noise=noise, duplicate_last=last_step is None,
+                                      records=records)
             if self.fused:
                 raise RuntimeError("fused sampling requested but unavailable for this model / solver")
             self.last_path = "generic"

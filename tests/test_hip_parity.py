@@ -159,13 +159,31 @@ def test_sde_samplers_with_stored_noise(golden, dev):
         assert s.last_path == "fused" and len(res) == n
         parity(f"f4.{tag}.final", rel_l2(res[-1].cpu(), f[tag + ".final"]), 7e-4)
         parity(f"f4.{tag}.penultimate", rel_l2(res[-2].cpu(), f[tag + ".penultimate"]), 7e-4)
-    # Heun goes through the generic loop (network still on the HIP path)
+    # stochastic Heun (integrators.py:39-51): fused too (lsl_sample_ex: three extended records per step), against the reference's output;
+    # the generic per-step loop (fused=False: the network alone on the HIP path) gives the same states
     tag = "sde5.linear.Mean.Heun"
-    s = _sampler(net)
+    s = _sampler(net, keep_trajectory=True)
     fn = s.sample_sde(sampling_method="Heun", diffusion_form="linear", last_step="Mean", num_steps=5, noise=f[tag + ".noise"].to(dev))
     res = fn(init, net.forward, x_cond=xc, x_cond_mask=mask)
-    assert s.last_path == "generic" and net.last_path == "hip" and len(res) == 5
-    parity(f"f4.{tag}.final", rel_l2(res[-1].cpu(), f[tag + ".final"]), 1e-3)
+    assert s.last_path == "fused" and s.last_kernels == "general" and net.last_path == "hip" and len(res) == 5
+    parity(f"f4.{tag}.final", rel_l2(res[-1].cpu(), f[tag + ".final"]), 7e-4)
+    sg = _sampler(net, fused=False)
+    gen = sg.sample_sde(sampling_method="Heun", diffusion_form="linear", last_step="Mean", num_steps=5, noise=f[tag + ".noise"].to(dev))(
+        init, net.forward, x_cond=xc, x_cond_mask=mask)
+    assert sg.last_path == "generic" and len(gen) == 5
+    for i in range(5):
+        parity(f"f4.{tag}.state{i}.fused_vs_generic", rel_l2(res[i].cpu(), gen[i].cpu()), 2e-4)
+    # device noise: same seed -> same bits, and the sharded halves reproduce the whole batch (noise slice = Heun step, global element)
+    def heun_dev(lo, hi, seed):
+        sd = _sampler(net, seed=seed)
+        sd.elem_offset = lo * init[0].numel()
+        return sd.sample_sde(sampling_method="Heun", diffusion_form="linear", last_step="Mean", num_steps=5)(
+            init[lo:hi], net.forward, x_cond=xc[lo:hi], x_cond_mask=mask[lo:hi])[-1]
+    B = init.shape[0]
+    whole = heun_dev(0, B, 3)
+    assert torch.equal(whole, heun_dev(0, B, 3)) and not torch.equal(whole, heun_dev(0, B, 4))
+    if B > 1:
+        assert torch.equal(whole, torch.cat([heun_dev(0, 1, 3), heun_dev(1, B, 3)]))
 
 
 def test_cfg1_decoded_coordinates(golden, dev):

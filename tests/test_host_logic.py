@@ -355,3 +355,43 @@ def test_bench_eight_ranks_weak_scaling_lines(workload, batch, stride):
     assert out["config"]["batch_per_gpu"] == batch and out["config"]["global_batch"] == 8 * batch
     assert out["config"]["noise_elem_stride_per_rank"] == stride
     assert out["gather_ms"] is not None and out["value"] > 0
+
+
+@pytest.mark.parametrize("path,pred,form,last", [("GVP", "data", "linear", "Mean"), ("GVP", "data", "SBDM", "Euler"), ("GVP", "noise", "sigma", "Tweedie"),
+                                                 ("GVP", "score", "decreasing", None), ("VP", "data", "constant", "Mean")])
+def test_heun_records_reproduce_the_reference_heun_step(path, pred, form, last):
+    """The extended step records handed to lsl_sample_ex for the stochastic Heun sampler (three records per step: noise in + keep,
+    predictor, corrector with the kept state) interpreted on the CPU give the states of the reference's own Heun loop
+    (integrators.py:39-51, here the generic per-step loop of Sampler) for a model that is a known function of (x, t)."""
+    from lam_slide_amd import CreateTransport, Sampler, _lib
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(2, 3, 4, 5, generator=g, dtype=torch.float64)
+    n = 7
+    noise = torch.randn(n - 1, 2, 3, 4, 5, generator=g, dtype=torch.float64)
+
+    def model(x, t, **kw):
+        return torch.tanh(0.7 * x) * (1.0 + t.reshape(-1, 1, 1, 1).to(x.dtype)) - 0.2 * x
+
+    s = Sampler(CreateTransport(path, pred)(), fused=False)
+    kw = dict(sampling_method="Heun", diffusion_form=form, diffusion_norm=1.3, last_step=last, last_step_size=0.04, num_steps=n)
+    want = s.sample_sde(**kw, noise=noise)(x0, model)
+    rec, _ = s.heun_records(diffusion_form=form, diffusion_norm=1.3, last_step=last, last_step_size=0.04, num_steps=n)
+    x, saved, states = x0.clone(), None, {}
+    for (t, ax, am, aw, as_, flags, ni, ti) in rec:
+        tv = torch.full((x.shape[0],), t, dtype=torch.float64)
+        new = ax * x
+        if not flags & _lib.STEP_NO_NETWORK:
+            new = new + am * model(x, tv)
+        if aw != 0.0:
+            new = new + aw * noise[ni]
+        if as_ != 0.0:
+            new = new + as_ * saved
+        x = new
+        if flags & _lib.STEP_SAVE:
+            saved = x.clone()
+        if ti >= 0:
+            states[ti] = x.clone()
+    assert sorted(states) == list(range(n if last is not None else n - 1))
+    for i, st in states.items():
+        assert torch.isfinite(want[i]).all()
+        assert torch.allclose(st, want[i].double(), rtol=2e-5, atol=2e-6), (i, float((st - want[i]).abs().max()))
