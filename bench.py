@@ -240,8 +240,8 @@ def run_rank(args) -> int:
     for _ in range(args.warmup):
         one_step()
     # small-trajectory models run the trajectory-resident kernel (one launch per group of state updates, no per-kernel classes to
-    # bracket).  The timed region runs the product path as it ships: no profiler, two lanes for large batches (the library overlaps the
-    # two half-batches on two streams); the per-kernel HIP-event timings of the roofline come from a separate pass afterwards
+    # bracket).  The timed region runs the product path as it ships, without the profiler; the per-kernel HIP-event timings of the
+    # roofline come from a separate pass afterwards
     resident = (not stub) and lib.lsl_sampler_path(net._handle, T, L) == 1
     fence()
     t0 = time.perf_counter()
@@ -352,8 +352,7 @@ def run_rank(args) -> int:
                 continue
         return None, None
 
-    how = ("separate sampling call after the timed region, per-launch HIP events on the launch stream, all passes on one stream "
-           "(un-overlapped; the timed region itself overlaps two half-batches on two streams)")
+    how = "separate sampling call after the timed region, per-launch HIP events on the launch stream (one stream, nothing co-running)"
     traffic, traffic_src = committed_traffic({0: "linear1", 1: "linear2"}.get(args.profile_kernel))
     step_ms = dt / args.steps * 1e3
     out["roofline"] = {

@@ -138,13 +138,14 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
 
 int env_int(const char *name, int dflt);
 int tune_int(const char *name, int dflt);
-// Two lanes: the passes of a large batch alternate between the caller's stream and a second one, so that one half-batch's memory-bound
-// kernels (LayerNorm, attention, output head: a quarter of the step) and the tails of its persistent GEMM launches share the chip with
-// the other half's kernels: +1.4 % on the cfg-2 bench (profiles/r03_experiments.txt).  Only when each half still makes full-size
-// launches (>= 64 Ki tokens); results do not depend on it (a trajectory's bits are independent of the batch it is sampled in).
-// LSL_LANES=1 (documented runtime switch) keeps everything on the caller's stream.
+// Two lanes (opt-in, LSL_LANES=2): the passes of a large batch alternate between the caller's stream and a second one, so that one
+// half-batch's memory-bound kernels (LayerNorm, attention, output head: a quarter of the step) and the tails of its persistent GEMM launches
+// share the chip with the other half's kernels: +1.4 % on the cfg-2 bench (profiles/r03_experiments.txt).  Only when each half still
+// makes full-size launches (>= 64 Ki tokens); results do not depend on it (a trajectory's bits are independent of the batch it is sampled
+// in).  Off by default: co-running kernels stretch each other's durations (k_linear1_ts 0.34 -> 0.46 ms in a rocprofv3 kernel trace), so a
+// profile of the default configuration would no longer show per-kernel times that can be compared with a roofline.
 int n_lanes() {
-    static const int l = env_int("LSL_LANES", 2);
+    static const int l = env_int("LSL_LANES", 1);
     return l >= 2 ? 2 : 1;
 }
 int lanes_for(int B, int T, int L) { return n_lanes() == 2 && B >= 2 && (size_t)B * T * L >= (size_t)131072 ? 2 : 1; }
