@@ -42,6 +42,7 @@ struct Lin1Args {
     float inv_hd, q_premul;
     int nt;                         // streaming stores
     unsigned long long *dbg;        // timing-probe builds only (LIN1_PROBE & 128): per workgroup and wave, 4 cycle sums; else unused
+    int wpt;                        // 0: the (tile, block) sequence is cut evenly over the grid; > 0: wpt workgroups per token tile, grid = wpt x tiles
 };
 
 template <int HDP, int K>
@@ -106,7 +107,19 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     const int NB = g.F >> 5;  // weight blocks (F is a multiple of 64: sections start on multiples of 64)
     const int ntile = (g.N + 255) >> 8;
     const long U = (long)ntile * NB;
-    const long i0 = (U * blockIdx.x / gridDim.x) & ~1L, i1 = blockIdx.x + 1 == gridDim.x ? U : ((U * (blockIdx.x + 1) / gridDim.x) & ~1L);
+    // Work split.  Large launches: the (tile, block) sequence cut evenly (on even blocks: sections start on multiples of 64 features and
+    // blocks alternate accumulators) over the persistent workgroups; a range that crosses a tile boundary pays a second segment
+    // (activation load, pipeline fill, drain).  Small launches (fewer tiles than workgroups): wpt workgroups share a tile, every range is
+    // ONE segment - the longest workgroup, which sets the launch time, no longer has two.
+    long i0, i1;
+    if (g.wpt > 0) {
+        const int tile = blockIdx.x / g.wpt, part = blockIdx.x - tile * g.wpt;
+        i0 = (long)tile * NB + ((NB * part / g.wpt) & ~1);
+        i1 = (long)tile * NB + (part + 1 == g.wpt ? NB : ((NB * (part + 1) / g.wpt) & ~1));
+    } else {
+        i0 = (U * blockIdx.x / gridDim.x) & ~1L;
+        i1 = blockIdx.x + 1 == gridDim.x ? U : ((U * (blockIdx.x + 1) / gridDim.x) & ~1L);
+    }
     if (i0 >= i1) return;  // (uniform)
 
     // In an 8-wave workgroup the second-dispatched half loses the issue arbitration on every SIMD (priority, then age): measured, waves 4-7

@@ -396,10 +396,17 @@ template <int HDP, int K>
 void launch_linear1_ts_t(const Lin1Args &a, hipStream_t st) {
     auto kern = k_linear1_ts<HDP, K>;
     LSL_ALLOW_LDS(kern, (size_t)163840);
-    const long units = (long)((a.N + 255) / 256) * (a.F / 32);
-    const int grid = (int)std::min<long>(device_cus(), units / 2);
+    const int ntile = (a.N + 255) / 256, nb = a.F / 32;
+    const long units = (long)ntile * nb;
+    int grid = (int)std::min<long>(device_cus(), units / 2);
+    Lin1Args b = a;
+    // fewer tiles than workgroups: whole workgroups per tile, one segment each (k_lin1.hip.h "Work split"); same bits either way
+    static const int align = tune_int("LSL_LIN1_ALIGN", 1);
+    const int wpt = std::min(device_cus() / ntile, nb / 2);
+    b.wpt = align && wpt >= 2 ? wpt : 0;
+    if (b.wpt) grid = b.wpt * ntile;
     const size_t lds = Lin1Cfg<HDP, K>::lds_bytes(a.F);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, b);
 }
 bool linear1_ts_ok(int hdp, int D, int F1, int HHD, int N) {
     static const int on = tune_int("LSL_LIN1_TS", 1);
@@ -491,6 +498,9 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
         case 11: return launch_gemm_glds<128, 128, 2, 2, 64, 2, false>(g, epi, st);
 #ifdef LSL_EXPERIMENTS
+        case 16: return launch_gemm_glds<128, 256, 2, 4, 64, 2, false>(g, epi, st);  // 128 features x 256 tokens, 8 waves of 64 x 64
+        case 17: return launch_gemm_glds<128, 256, 2, 4, 32, 3, false>(g, epi, st);
+        case 18: return launch_gemm_glds<128, 256, 1, 8, 64, 2, false>(g, epi, st);  // 8 waves of 128 x 32
         case 13: return launch_gemm_glds<256, 128, 2, 2, 32, 2, true>(g, epi, st);
         case 14: return launch_gemm_glds<256, 128, 2, 2, 64, 2, true>(g, epi, st);  // 4 waves, one per SIMD, 64-deep k-tiles, one workgroup per CU
 #endif

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../lam_slide_amd/csrc/k_gemm.hip.h"
@@ -86,7 +87,11 @@ void run_case(int N, int D, int H, int mlp_ratio, int iters, int grid_new, int p
     const long units = (long)((N + 255) / 256) * (F / 32);
     int gnew = grid_new;
     if (gnew > units / 2) gnew = (int)(units / 2);
-    printf("  lds old %zu new %zu, grid old %d new %d\n", lds_old, lds_new, grid_old, gnew);
+    if (getenv("LIN1_WPT")) {  // tile-aligned split for small launches, as launch_linear1_ts_t chooses it
+        const int ntile = (N + 255) / 256, wpt = std::min(256 / ntile, F / 64);
+        if (wpt >= 2) { la.wpt = wpt; gnew = wpt * ntile; }
+    }
+    printf("  lds old %zu new %zu, grid old %d new %d (wpt %d)\n", lds_old, lds_new, grid_old, gnew, la.wpt);
 
     hipLaunchKernelGGL(kold, dim3(grid_old), dim3(512), lds_old, 0, ga, e);
     CK(hipDeviceSynchronize());
