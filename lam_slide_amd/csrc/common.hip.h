@@ -48,6 +48,7 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {  // one v_cvt_pk
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ u32x4 as_u32x4(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -75,6 +75,9 @@ enum { LIN1_QK = 0, LIN1_V = 1, LIN1_MLP = 2 };
 #ifndef LIN1_PRIO
 #define LIN1_PRIO 0
 #endif
+#ifndef LIN1_XLOAD
+#define LIN1_XLOAD 1  // 1: K <= 256: activations loaded as whole cache lines and transposed through the staging image; 0: fragment-shaped loads
+#endif
 #ifndef LIN1_PD
 #define LIN1_PD 3  // A fragments requested this many k-steps ahead of their MFMA
 #endif
@@ -421,10 +424,33 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         row_q = reinterpret_cast<const char *>(g.qkv) + (size_t)n_wave * stride_q;
         row_z = reinterpret_cast<const char *>(g.z) + (size_t)n_wave * stride_z - 4 * (size_t)g.HHD;  // (z column of feature f: f - 2 HHD)
         // the wave's tokens: B fragments of all k-steps (X is padded to whole tiles)
+        // Whole 128-byte lines per 8 lanes (8 rows x 128 B per instruction: 8 cache lines, where the fragment-shaped load of a k-step
+        // touches 32), then line by line through the wave's staging image into fragment order, in place: line j of every row holds the
+        // k-steps 4 j .. 4 j + 3.  Chunk c of row t sits at t 128 + 16 (c ^ ((t >> 1) & 7)): conflict-free for both accesses.
         if (!(LIN1_PROBE & 32) || i == i0) {
-            const u16 *xr = g.X + (size_t)(n_wave + r) * K + 8 * hf;
+            if (LIN1_XLOAD == 0 || K > 256) {  // (K = 384 / 512: the kernel is at its register limit and the staging pass costs more than it saves: measured)
+                const u16 *xr = g.X + (size_t)(n_wave + r) * K + 8 * hf;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xreg[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + 16 * ks));
+                for (int ks = 0; ks < KS; ++ks) xreg[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + 16 * ks));
+            } else {
+                const u16 *xr = g.X + (size_t)(n_wave + (lane >> 3)) * K + 8 * (lane & 7);
+#pragma unroll
+                for (int j = 0; j < KS / 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xreg[4 * j + q] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + (size_t)(8 * q) * K + 64 * j));
+                const unsigned t0 = lane >> 3;  // row of instruction q: t0 + 8 q, (row >> 1) & 7 = ((t0 >> 1) + 4 q) & 7
+                const unsigned xw = (unsigned)(size_t)(LDS_PTR(char))(stage) + t0 * 128;
+                const unsigned xr0 = (unsigned)(size_t)(LDS_PTR(char))(stage) + r * 128;
+#pragma unroll
+                for (int j = 0; j < KS / 4; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<LDS_PTR(u32x4)>(xw + 1024 * q + ((((lane & 7) ^ ((t0 >> 1) + 4 * q)) & 7) << 4)) = as_u32x4(xreg[4 * j + q]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        xreg[4 * j + m] = as_bf16x8(*reinterpret_cast<const LDS_PTR(u32x4)>(xr0 + ((((2 * m + hf) ^ (r >> 1)) & 7) << 4)));
+                }
+            }
         }
         const unsigned nn = (unsigned)min(n_wave + r, g.N - 1);
         const unsigned n1 = g.div_magic ? __umulhi(nn, g.div_magic) : nn;

@@ -158,6 +158,7 @@ int main(int argc, char **argv) {
     else if (D == 256 && hdp == 16) run_case<16, 256>(N, D, H, mr, iters, grid, pos_mode);
     else if (D == 256 && hdp == 32) run_case<32, 256>(N, D, H, mr, iters, grid, pos_mode);
     else if (D == 128 && hdp == 32) run_case<32, 128>(N, D, H, mr, iters, grid, pos_mode);
+    else if (D == 384 && hdp == 32) run_case<32, 384>(N, D, H, mr, iters, grid, pos_mode);
     else printf("unsupported shape\n");
     return 0;
 }
