@@ -25,6 +25,7 @@ struct AttnArgs {
     int nt;          // streaming stores for the output (common.hip.h: store8)
     int hd;          // true head_dim (<= HDP).  hd < HDP (peptide: 24 of 32): the padding channels of v are zero, and k_attention_rows
                      // turns channel hd of the staged V into ones, so that row hd of O^T = V^T P^T IS the softmax denominator
+    int bound;       // k_attention_rows: 1 = softmax shifted by the Cauchy-Schwarz bound |q| max|k| instead of the row maximum when that is safe
 };
 
 template <int HDP>
@@ -184,6 +185,14 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
 #pragma unroll
         for (int s = 0; s < KS; ++s) qf0[s] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qrow + 16 * s + 8 * hf));
     }
+    // Softmax shift without a max pass (a.bound): softmax is invariant under any per-query shift, and |s_ij| <= |q_i| |k_j| <= |q_i| max_j |k_j| =: m_i
+    // costs O(S hd) instead of the S^2 score recomputation + one v_max per score of the max pass (this kernel is bound by its vector
+    // instructions: 5.5 issue slots per score with the max pass, 4.5 without).  exp2(s - m_i) lies in [2^(-2 m_i), 1]: no underflow while
+    // m_i <= 60 (q and k are RMS-normalised: m_i ~ 1.44 sqrt(hd) w_q w_k, about 8 for unit norm weights); a query tile with a larger bound
+    // takes the max pass (wave-uniform).  The probabilities differ from the max-shifted ones by a per-query power-of-two-ish factor that
+    // cancels in O / l; bf16 / fp32 relative precision does not depend on it.
+    float kmax2 = 0.0f;
+    float *const red = reinterpret_cast<float *>(smem + (size_t)ITEMS * 2 * Sp * ROWB);  // NW floats behind K / V (sized by the launcher)
     {
         const int ltid = wsub * 64 + lane, lthreads = WPI * 64;
         const u16 *kbase = a.qkv + tok0 * rs + a.HHD + head * HDP;
@@ -202,9 +211,30 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
             }
             *reinterpret_cast<u32x4 *>(Ks + k_swz<HDP>(row, ch)) = kv;
             *reinterpret_cast<u32x4 *>(Vs + row * ROWB + ch * 16) = vv;
+            if (a.bound) {  // squared norm of the key row: its CPR chunks sit on CPR neighbouring lanes
+                float ss = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __uint_as_float(kv[k] << 16), hi = __uint_as_float(kv[k] & 0xffff0000u);
+                    ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+                }
+                ss += __shfl_xor(ss, 1, 64);
+                if (CPR == 4) ss += __shfl_xor(ss, 2, 64);
+                kmax2 = fmaxf(kmax2, ss);
+            }
         }
     }
+    if (a.bound) {
+#pragma unroll
+        for (int m = 32; m >= CPR; m >>= 1) kmax2 = fmaxf(kmax2, __shfl_xor(kmax2, m, 64));
+        if (lane == 0) red[wave] = kmax2;
+    }
     __syncthreads();
+    if (a.bound) {
+        kmax2 = red[item_local * WPI];
+#pragma unroll
+        for (int w = 1; w < WPI; ++w) kmax2 = fmaxf(kmax2, red[item_local * WPI + w]);
+    }
 
     const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, grp = lane >> 4;
     const int v_off = (4 * (grp >> 1) + gq) * ROWB + ((HDP == 32 ? (grp & 1) * 16 : 0) + 4 * gp) * 2;
@@ -238,13 +268,32 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
             return t;
         };
         float mx = -INFINITY;
-#pragma unroll 2
-        for (int kt = 0; kt < nkt; ++kt) {
-            const f32x16 t = scores(kt, zero);
+        bool shifted = false;
+        if (a.bound) {
+            float qq = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[e]);
+            for (int s2 = 0; s2 < KS; ++s2) {
+                const u32x4 w = __builtin_bit_cast(u32x4, qf[s2]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+                    qq = fmaf(lo, lo, fmaf(hi, hi, qq));
+                }
+            }
+            qq += xhalf(qq);
+            const float m = sqrtf(qq * kmax2) * 1.001f;
+            shifted = __ballot(m > 60.0f) == 0;  // (wave-uniform)
+            if (shifted) mx = m;
         }
-        mx = fmaxf(mx, xhalf(mx));
+        if (!shifted) {
+#pragma unroll 2
+            for (int kt = 0; kt < nkt; ++kt) {
+                const f32x16 t = scores(kt, zero);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[e]);
+            }
+            mx = fmaxf(mx, xhalf(mx));
+        }
         // pass 2: the row maximum is subtracted by the MFMA itself (accumulator preset to -max), and the row sum comes out of a
         // third MFMA against an all-ones operand (sum over keys of the SAME bf16 probabilities that multiply V) - two VALU
         // operations less per score element, and this kernel is VALU-bound at head_dim 32

@@ -229,6 +229,21 @@ int device_cus();
 int env_int(const char *name, int dflt);
 
 template <int NE, int VEC>
+void launch_head_mfma(float *x, float *out, const float *h, const float *shift, const float *scale, int stride, const float *Wo,
+                      const float *bo, int n, int C, int tpt, int do_step, float ax, float am, float aw, const float *noise,
+                      unsigned long long seed, unsigned step, unsigned long long eo, float *trace, float as, const float *saved, float *save_out,
+                      hipStream_t st) {
+    auto kern = k_head_step_mfma<NE, VEC>;
+    constexpr size_t lds = head_mfma_lds_bytes<NE>();
+    LSL_ALLOW_LDS(kern, lds);
+    // two workgroups per CU where the LDS image allows it (hidden <= 384): one workgroup's LayerNorm / weight-load latencies under the other's MFMAs
+    static const int per_cu = tune_int("LSL_HEAD_PER_CU", 2);
+    const int wgs = device_cus() * (per_cu >= 2 && 2 * lds <= (size_t)160 * 1024 ? 2 : 1);
+    hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, wgs)), dim3(256), lds, st, x, out, h, shift, scale, stride,
+                       Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace, as, saved, save_out);
+}
+
+template <int NE, int VEC>
 void launch_head_t(float *x, float *out, const float *h, const float *shift, const float *scale, int stride, const float *Wo,
                    const float *bo, int n, int C, int tpt, int do_step, float ax, float am, float aw, const float *noise,
                    unsigned long long seed, unsigned step, unsigned long long eo, float *trace, float as, const float *saved, float *save_out,
@@ -244,11 +259,7 @@ void launch_head_t(float *x, float *out, const float *h, const float *shift, con
         return;
     }
 #endif
-    auto kern = k_head_step_mfma<NE, VEC>;
-    constexpr size_t lds = head_mfma_lds_bytes<NE>();
-    LSL_ALLOW_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, device_cus())), dim3(256), lds, st, x, out, h, shift, scale, stride,
-                       Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace, as, saved, save_out);
+    launch_head_mfma<NE, VEC>(x, out, h, shift, scale, stride, Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace, as, saved, save_out, st);
 }
 
 #define DISPATCH_D(D, FN, ...)                          \
@@ -515,7 +526,7 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
 template <int HDP, int NW, int ITEMS, int NKT>
 void launch_attention_rows(const AttnArgs &a, hipStream_t st) {
     auto kern = k_attention_rows<HDP, NW, ITEMS, NKT>;
-    const size_t lds = (size_t)ITEMS * 2 * (NKT > 0 ? NKT * 32 : (a.S + 31) & ~31) * HDP * 2;
+    const size_t lds = (size_t)ITEMS * 2 * (NKT > 0 ? NKT * 32 : (a.S + 31) & ~31) * HDP * 2 + NW * sizeof(float);  // K, V, key-norm slots
     LSL_ALLOW_LDS(kern, NKT > 0 ? lds : (size_t)160 * 1024);
     const long items = (long)a.n_seq * a.H;
     hipLaunchKernelGGL(kern, dim3((unsigned)((items + ITEMS - 1) / ITEMS)), dim3(NW * 64), lds, st, a);
@@ -530,7 +541,12 @@ void launch_attention_t(const AttnArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((k_attention_tiny<HDP>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, a);
         return;
     }
-    if (!online && (size_t)2 * Sp * HDP * 2 <= (size_t)160 * 1024) {  // two-pass softmax, K/V of one (sequence, head) in LDS
+    if (!online && (size_t)2 * Sp * HDP * 2 + 64 <= (size_t)160 * 1024) {  // two-pass softmax, K/V of one (sequence, head) in LDS
+        // long axes (peptide T = 1000): 16 waves - with the max pass gone (AttnArgs::bound) the kernel is a chain of MFMA -> exp2 -> MFMA per
+        // tile, and four waves per SIMD hide it better than two (attention 320.6 -> 303.8 ms per 1000-step call; with the max pass
+        // 8 waves were as fast, profiles/r02_experiments.txt)
+        static const int nw16 = tune_int("LSL_ATTN_NW16", 1);
+        if (Sp > 256 && nw16) return launch_attention_rows<HDP, 16, 1, 0>(a, st);
         if (Sp > 256) return launch_attention_rows<HDP, 8, 1, 0>(a, st);
         if (Sp <= 32) return launch_attention_rows<HDP, 4, 4, 1>(a, st);
         if (Sp <= 64) return launch_attention_rows<HDP, 4, 2, 2>(a, st);
@@ -688,6 +704,8 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     aa.zw = m->K2;
     aa.H = d.heads;
     aa.hd = d.head_dim;
+    static const int attn_bound = tune_int("LSL_ATTN_BOUND", 1);
+    aa.bound = attn_bound == 2 || (attn_bound == 1 && (temporal ? T : L) > 96);  // short axes: the max pass is one or two tiles, cheaper than the norms
     if (!temporal) {  // sequences (b,t), positions l
         aa.S = L; aa.n_seq = bc * T; aa.inner = 1; aa.outer_stride = L; aa.pos_stride = 1;
     } else {          // sequences (b,l), positions t

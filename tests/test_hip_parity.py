@@ -442,6 +442,32 @@ def test_forward_edge_shapes_vs_oracle(name, dev):
     parity(f"edge.{name}", rel_l2(got, want), 4e-4)
 
 
+@pytest.mark.parametrize("gain", [1.0, 2.5, 6.0], ids=["unit", "x2.5", "x6"])
+def test_attention_softmax_shift_bound_and_fallback(gain, dev):
+    """k_attention_rows shifts the softmax by the Cauchy-Schwarz bound |q| max|k| instead of the row maximum while that bound is <= 60
+    (k_attn.hip.h); larger bounds take the max pass.  QK-norm scales multiplied by `gain` (both q and k: scores x gain^2) walk through
+    the regimes: bound ~ 8 (shifted), ~ 50 (shifted, probabilities down to 2^-100), ~ 290 (max pass).  Axes of 40 and 300 positions
+    run the short-sequence and the run-time-length instance."""
+    from oracle import latent_net
+    kw = dict(depth=1, in_dim=16, hidden_size=128, num_heads=4, mlp_ratio=2)
+    B, T, L = 2, 300, 40
+    sh = latent_net.NetShape(**kw)
+    p = latent_net.random_params(sh, seed=31)
+    for k in p:
+        if k.endswith("query_norm.scale") or k.endswith("key_norm.scale"):
+            p[k] = p[k] * gain
+    net = build_net(sh, p, dev)
+    g = torch.Generator().manual_seed(9)
+    x, xc = torch.randn(B, T, L, sh.in_dim, generator=g), torch.randn(B, T, L, sh.in_dim, generator=g)
+    mask = (torch.rand(B, T, L, generator=g) < 0.4).long()
+    t = torch.rand(B, generator=g)
+    want = latent_net.forward(p, sh, x, t, xc, mask, None)
+    got = net(x.to(dev), t.to(dev), xc.to(dev), mask.to(dev), None).cpu()
+    assert torch.isfinite(got).all()
+    # sharper softmaxes amplify the bf16 rounding of q and k (d softmax / d score ~ score range): the bar follows the gain
+    parity(f"attn_shift.gain{gain}", rel_l2(got, want), 4e-4 * max(1.0, gain * gain / 2))
+
+
 def test_full_chain_encode_sample_decode_on_device(golden, dev):
     """Everything SecondStageCondLightningBase.sample does after prepare_inputs (lightning_base.py:217-238 with second_stage/md17.py:
     115-131), on the device: Stage1Encoder -> setup_conditioning -> fused sampler -> Stage1Decoder, against the same chain on the
