@@ -509,6 +509,9 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
         case 11: return launch_gemm_glds<128, 128, 2, 2, 64, 2, false>(g, epi, st);
 #ifdef LSL_EXPERIMENTS
+        case 23: return launch_gemm_glds<512, 128, 4, 2, 32, 3, false>(g, epi, st);  // whole residual rows per workgroup (F = 512): 120 KiB ring
+        case 24: return launch_gemm_glds<512, 128, 4, 2, 32, 2, false>(g, epi, st);
+        case 25: return launch_gemm_glds<512, 128, 4, 2, 32, 3, true>(g, EpiPieces<Epi>(epi), st);
         case 16: return launch_gemm_glds<128, 256, 2, 4, 64, 2, false>(g, epi, st);  // 128 features x 256 tokens, 8 waves of 64 x 64
         case 17: return launch_gemm_glds<128, 256, 2, 4, 32, 3, false>(g, epi, st);
         case 18: return launch_gemm_glds<128, 256, 1, 8, 64, 2, false>(g, epi, st);  // 8 waves of 128 x 32
