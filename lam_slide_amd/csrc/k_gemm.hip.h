@@ -412,6 +412,7 @@ struct EpiLinear1 {
             }
         }
     }
+#ifdef LSL_EXPERIMENTS  // (the piece form of this epilogue is used by rejected GEMM structures only: tools/build_experiments.sh)
     // ---- the same epilogue as 16 software-pipelined pieces of a 128-feature x 64-token wave tile (k_gemm_pp.hip.h), where the
     // epilogue runs on ONE wave per SIMD and nothing but the wave's own instruction stream can hide latency.
     // Piece C = rows 16 (C & 1) .. +15 of the 32 x 32 accumulator tile [i = C >> 2][j = (C >> 1) & 1].  The tile is transposed
@@ -505,6 +506,7 @@ struct EpiLinear1 {
             *reinterpret_cast<u32x4 *>(dst) = pk;  // 64 contiguous bytes per token row: half lines, no streaming stores (they need whole lines)
         }
     }
+#endif
 };
 
 // linear2 epilogue: h[n][f] += gate[b][f] * (acc + bias[f])   (latent_si_v31.py:53,60; fp32 residual)

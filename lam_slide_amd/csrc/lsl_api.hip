@@ -162,6 +162,10 @@ int default_chunk(const lsl_model *m, int B, int T, int L) {
     size_t c = (size_t)262144 / ((size_t)T * L ? (size_t)T * L : 1);
     if (c < 1) c = 1;
     if (c > (size_t)B) c = B;
+    {  // equal passes: 1024 trajectories of 640 tokens are 342 + 342 + 340, not 409 + 409 + 206 (the short pass fills the chip worse)
+        const size_t passes = ((size_t)B + c - 1) / c;
+        c = ((size_t)B + passes - 1) / passes;
+    }
     if (lanes_for(B, T, L) == 2 && c > (size_t)(B + 1) / 2) c = (B + 1) / 2;  // at least one pass per lane
     return (int)c;
 }
@@ -502,8 +506,17 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     if (variant == 22 && pp_ok && launch_gemm_pp<64, 3>(g, epi, st)) return;
 #endif
     if (variant == 12 && K % 128 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, epi, st);  // 5 made persistent (staging in ring slot 1)
-    if (variant == 7 && F % 32 == 0 && pp_ok && K % 128 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, EpiPieces<Epi>(epi), st);  // persistent, 64-deep k-tiles, piece epilogue
-    if (variant == 8 && F % 32 == 0 && pp_ok) return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, EpiPieces<Epi>(epi), st);  // variant 6 with the piece epilogue
+#ifdef LSL_EXPERIMENTS
+    constexpr bool pieces_ok = true;
+#else
+    constexpr bool pieces_ok = std::is_same<Epi, EpiLinear2>::value;  // (linear1's piece epilogue exists in the experiments build only)
+#endif
+    if constexpr (pieces_ok) {
+        if (variant == 7 && F % 32 == 0 && pp_ok && K % 128 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, EpiPieces<Epi>(epi), st);  // persistent, 64-deep k-tiles, piece epilogue
+#ifdef LSL_EXPERIMENTS
+        if (variant == 8 && F % 32 == 0 && pp_ok) return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, EpiPieces<Epi>(epi), st);  // variant 6 with the piece epilogue
+#endif
+    }
     switch (variant) {
         case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);

@@ -146,6 +146,28 @@ def test_ode_samplers_against_reference_outputs(golden, dev):
         parity(f"f4.ode6.{path}.{pred}", rel_l2(res[-1].cpu(), f[f"ode6.{path}.{pred}"]), 6e-4)
 
 
+def test_ode_dopri5_default_method_on_the_hip_network(golden, dev):
+    """The reference's default ODE method (adaptive dopri5, transport.py:486-494) with every network evaluation on the HIP path, against
+    the same solver driven by the pinned oracle network on the CPU.  torchdiffeq itself is absent (parity unpinned against it; the solver
+    is checked against scipy and exact solutions in the CPU suite): two rtol = 1e-3 solves may choose different steps, so the bar is the
+    solver tolerance, not the kernel rounding."""
+    from oracle import latent_net
+    f = golden("f4_sampler.npz")
+    sh = shape_from(f.group("shape"))
+    p = f.group("p")
+    net = build_net(sh, p, dev)
+    init, xc, mask = f["init"], f["x_cond"], f["mask"]
+    for path, pred in (("GVP", "data"), ("Linear", "velocity")):
+        s = _sampler(net, path, pred)
+        res = s.get_sample_fn("ODE", {"num_steps": 8})(init.to(dev), net, x_cond=xc.to(dev), x_cond_mask=mask.to(dev))
+        assert s.last_path == "dopri5" and len(res) == 8 and net.last_path == "hip"
+        so = _sampler(net, path, pred)
+        want = so.get_sample_fn("ODE", {"num_steps": 8})(init, lambda x, t, **kw: latent_net.forward(p, sh, x, t, kw["x_cond"], kw["x_cond_mask"], None),
+                                                         x_cond=xc, x_cond_mask=mask)
+        parity(f"f4.dopri5.{path}.{pred}", rel_l2(res[-1].cpu(), want[-1]), 5e-3)
+        assert abs(s.last_ode_stats["accepted"] - so.last_ode_stats["accepted"]) <= 2
+
+
 def test_sde_samplers_with_stored_noise(golden, dev):
     f = golden("f4_sampler.npz")
     sh = shape_from(f.group("shape"))

@@ -395,3 +395,70 @@ def test_heun_records_reproduce_the_reference_heun_step(path, pred, form, last):
     for i, st in states.items():
         assert torch.isfinite(want[i]).all()
         assert torch.allclose(st, want[i].double(), rtol=2e-5, atol=2e-6), (i, float((st - want[i]).abs().max()))
+
+
+# ---- adaptive dopri5 (the reference's default ODE method; torchdiffeq absent: parity unpinned, checked against scipy and exact solutions) ----
+def test_dopri5_solver_against_exact_solution_and_scipy():
+    import numpy as np
+    from scipy.integrate import solve_ivp
+
+    from lam_slide_amd.transport import dopri5_solve
+    A = torch.tensor([[-0.5, 2.0, 0.0], [-2.0, -0.5, 0.3], [0.0, -0.3, -0.1]], dtype=torch.float64)
+
+    def f(t, y):  # stiff-free linear system with a time-dependent forcing, batch of 4 states
+        return y @ A.T + torch.sin(torch.tensor(3.0 * t, dtype=torch.float64)) * torch.tensor([1.0, 0.0, -1.0], dtype=torch.float64)
+
+    y0 = torch.tensor([[1.0, 0.0, 0.5], [0.2, -1.0, 0.0], [0.0, 0.0, 0.0], [3.0, 1.0, -2.0]], dtype=torch.float64)
+    grid = np.linspace(0.0, 2.0, 9)
+    for rtol, atol in ((1e-3, 1e-6), (1e-6, 1e-9)):
+        ys, st = dopri5_solve(f, y0, list(grid), rtol, atol)
+        ref = solve_ivp(lambda t, y: f(t, torch.from_numpy(y).reshape(4, 3)).reshape(-1).numpy(), (0.0, 2.0), y0.reshape(-1).numpy(),
+                        method="DOP853", rtol=1e-12, atol=1e-14, t_eval=grid)
+        sp = solve_ivp(lambda t, y: f(t, torch.from_numpy(y).reshape(4, 3)).reshape(-1).numpy(), (0.0, 2.0), y0.reshape(-1).numpy(),
+                       method="RK45", rtol=rtol, atol=atol, t_eval=grid)
+        got = torch.stack(ys).reshape(len(grid), -1).numpy()
+        err = np.abs(got - ref.y.T).max()
+        err_sp = np.abs(sp.y.T - ref.y.T).max()
+        assert err < 30 * rtol, (rtol, err)                  # global error of an rtol-controlled solve
+        assert err < 5 * err_sp + 10 * atol, (err, err_sp)   # same class of accuracy as scipy's Dormand-Prince at the same tolerances
+        assert st["accepted"] >= 3 and st["nfe"] == 2 + 6 * (st["accepted"] + st["rejected"])
+        assert abs(st["accepted"] + st["rejected"] - sp.nfev / 6) <= 0.35 * sp.nfev / 6 + 3  # same controller family: similar step counts
+    # outputs are interpolated inside steps, not stepped to: a grid much finer than the steps costs no evaluations
+    ys_f, st_f = dopri5_solve(f, y0, list(np.linspace(0.0, 2.0, 201)), 1e-3, 1e-6)
+    ys_c, st_c = dopri5_solve(f, y0, [0.0, 2.0], 1e-3, 1e-6)
+    assert st_f["nfe"] == st_c["nfe"] and torch.allclose(ys_f[-1], ys_c[-1], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("path,pred,reverse", [("GVP", "data", False), ("Linear", "velocity", False), ("VP", "noise", False)])
+def test_sample_ode_dopri5_default_method_runs_and_converges(path, pred, reverse):
+    """get_sample_fn("ODE", {}) - the reference's defaults (dopri5, 50 outputs, atol 1e-6, rtol 1e-3) - on a callable model: same states as
+    a float64 solve of the same ODE at rtol 1e-9 within the solver tolerance (the stiff GVP / VP ends near t = 1 included, where a 4000-step
+    Euler solve is off by 30 %), 50 outputs, state 0 = the initial noise."""
+    from lam_slide_amd import CreateTransport, Sampler
+    torch.manual_seed(0)
+    W = torch.randn(6, 6) * 0.3
+
+    def model(x, t, **kw):
+        return torch.tanh(x @ W.to(x.dtype)) * (1.0 + t.to(x.dtype).view(-1, 1, 1)) - 0.2 * x
+
+    init = torch.randn(3, 5, 6)
+    s = Sampler(CreateTransport(path, pred)())
+    kw = {"reverse": True} if reverse else {}
+    out = s.get_sample_fn("ODE", dict(kw))(init, model)
+    assert out.shape == (50, 3, 5, 6) and torch.equal(out[0], init) and s.last_path == "dopri5"
+    stats = dict(s.last_ode_stats)
+    tight = s.get_sample_fn("ODE", dict(kw, rtol=1e-9, atol=1e-12))(init.double(), model)
+    for i in (10, 25, 49):
+        scale = float(tight[i].abs().max())
+        assert float((out[i] - tight[i]).abs().max()) < 1e-2 * scale, (i, scale)
+    assert stats["accepted"] >= 3 and s.last_ode_stats["nfe"] > stats["nfe"]
+
+
+def test_sample_ode_reverse_asserts_like_the_reference():
+    """reverse=True turns the interval into (1 - t0, 1 - t1) and the reference's ode class then asserts t0 < t1 (integrators.py:67-70):
+    the same AssertionError for both native methods."""
+    from lam_slide_amd import CreateTransport, Sampler
+    s = Sampler(CreateTransport("Linear", "velocity")())
+    for method in ("euler", "dopri5"):
+        with pytest.raises(AssertionError):
+            s.sample_ode(sampling_method=method, reverse=True)
