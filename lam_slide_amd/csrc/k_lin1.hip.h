@@ -67,7 +67,7 @@ struct Lin1Cfg {
 enum { LIN1_QK = 0, LIN1_V = 1, LIN1_MLP = 2 };
 
 // Timing probes for tools/lin1_harness.hip ONLY (compile-time; results wrong when set; the library is built without the macro):
-// 1 no epilogue arithmetic, 2 no MFMAs / fragment reads, 4 no output stores, 8 no weight DMA, 16 no per-block wait + barrier, 32 no activation loads,
+// 1 no epilogue arithmetic, 2 no MFMAs / fragment reads, 4 no output stores, 8 no weight DMA, 16 no per-block wait + barrier,
 // 64 no fragment reads inside the MFMA chain, 128 cycle stamps per step phase into Lin1Args::dbg
 #ifndef LIN1_PROBE
 #define LIN1_PROBE 0
@@ -76,7 +76,13 @@ enum { LIN1_QK = 0, LIN1_V = 1, LIN1_MLP = 2 };
 #define LIN1_PRIO 0
 #endif
 #ifndef LIN1_XLOAD
-#define LIN1_XLOAD 1  // 1: K <= 256: activations loaded as whole cache lines and transposed through the staging image; 0: fragment-shaped loads
+#define LIN1_XLOAD 1  // 1: activations loaded as whole cache lines and transposed through the staging image; 0: fragment-shaped loads
+#endif
+#ifndef LIN1_DRAIN_NT
+#define LIN1_DRAIN_NT 1
+#endif
+#ifndef LIN1_ALL_PLAIN
+#define LIN1_ALL_PLAIN 0
 #endif
 #ifndef LIN1_PD
 #define LIN1_PD 3  // A fragments requested this many k-steps ahead of their MFMA
@@ -184,7 +190,7 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
 
     // ring prologue: the first two blocks of the range
     {
-        int b = (int)(i0 % NB);
+        int b = (int)(i0 - (i0 / NB) * NB);
         issue(b, 0);
         advance(b);
         issue(b, 1);
@@ -241,8 +247,20 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     };
     auto flush_store = [&](int half, const u32x4 (&pk)[2]) __attribute__((always_inline)) {
         if (LIN1_PROBE & 4) return;
+        if (LIN1_ALL_PLAIN) {
+            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(fl_voff + (2 * half) * fl_stride8), "v"(pk[0]), "s"(fl_base) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(fl_voff + (2 * half + 1) * fl_stride8), "v"(pk[1]), "s"(fl_base) : "memory");
+            return;
+        }
         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(fl_voff + (2 * half) * fl_stride8), "v"(pk[0]), "s"(fl_base) : "memory");
         asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(fl_voff + (2 * half + 1) * fl_stride8), "v"(pk[1]), "s"(fl_base) : "memory");
+    };
+    auto flush_store_visible = [&](int half, const u32x4 (&pk)[2]) __attribute__((always_inline)) {
+        if (LIN1_PROBE & 4) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (LIN1_DRAIN_NT) __builtin_nontemporal_store(pk[i], reinterpret_cast<u32x4 *>(const_cast<char *>(fl_base) + (size_t)(fl_voff + (2 * half + i) * fl_stride8)));
+            else *reinterpret_cast<u32x4 *>(const_cast<char *>(fl_base) + (size_t)(fl_voff + (2 * half + i) * fl_stride8)) = pk[i];
     };
     auto put_group = [&](int ii, int q, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
         const u32x2 pk = {pack2(v0, v1), pack2(v2, v3)};
@@ -351,6 +369,19 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     std::integral_constant<int, 1> I1;
     auto no_side = [](auto) __attribute__((always_inline)) {};
     unsigned long long dbg_sum[4] = {0, 0, 0, 0};
+    unsigned long long dbg_seg[4] = {0, 0, 0, 0};  // (probe builds) per segment: activation load + wait + barrier, first two steps, drain + flush, count
+    auto kstamp = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    unsigned long long dbg_split[3] = {0, 0, 0};  // later segments: older operations done, activation loads done, barrier
+    unsigned long long dbg_ph[4] = {0, 0, 0, 0};  // later segments: compute-only step, all fused steps, next segment's requests, drain + flush
+    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
+    unsigned long long dbg_c0 = 0, dbg_r0 = 0;  // (probe builds) core-clock and constant 100 MHz stamps at kernel entry: the clock the chip holds
+    if (LIN1_PROBE & 128) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_c0), "=s"(dbg_r0)::"memory");
     // fused step: MFMAs of block e + 1 beside the epilogue of block e (parity PAR = e & 1, section SEC).  FLUSH (PAR == 0 steps except the first
     // of a segment): the slab (e - 2, e - 1) is complete in the staging image and leaves during this step; PREV_FLUSHED: the previous step did
     auto fused = [&](auto sec_c, auto par_c, auto flush_c, auto prev_c, int e) __attribute__((always_inline)) {
@@ -414,63 +445,87 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     std::integral_constant<int, LIN1_V> SV;
     std::integral_constant<int, LIN1_MLP> SMLP;
 
+    // The wave's tokens as B fragments of all k-steps (X is padded to whole tiles): whole 128-byte lines per 8 lanes (8 rows x 128 B per
+    // instruction: 8 cache lines, where a fragment-shaped load of one k-step touches 32 - the texture-address unit then needs ~ 58 cycles
+    // per instruction, 15 000 cycles for a workgroup's 256: measured), then - finish_x - line by line through the wave's staging image into
+    // fragment order, in place: line j of every row holds the k-steps 4 j .. 4 j + 3; chunk c of row t sits at t 128 + 16 (c ^ ((t >> 1) & 7)),
+    // conflict-free for both accesses.
+    constexpr bool XLINES = LIN1_XLOAD != 0 && (K <= 384 || LIN1_XLOAD == 2);  // (K = 512: 7 more spilled registers for - 1.7 %: not taken)
+    auto load_x = [&](int nw) __attribute__((always_inline)) {
+        if (!XLINES) {
+            const u16 *xr = g.X + (size_t)(nw + r) * K + 8 * hf;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xreg[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + 16 * ks));
+        } else {
+            const u16 *xr = g.X + (size_t)(nw + (lane >> 3)) * K + 8 * (lane & 7);
+#pragma unroll
+            for (int j = 0; j < KS / 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xreg[4 * j + q] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + (size_t)(8 * q) * K + 64 * j));
+        }
+    };
+    auto finish_x = [&]() __attribute__((always_inline)) {
+        if (!XLINES) return;
+        const unsigned t0 = lane >> 3;  // row of instruction q: t0 + 8 q, (row >> 1) & 7 = ((t0 >> 1) + 4 q) & 7
+        const unsigned xw = (unsigned)(size_t)(LDS_PTR(char))(stage) + t0 * 128;
+        const unsigned xr0 = (unsigned)(size_t)(LDS_PTR(char))(stage) + r * 128;
+#pragma unroll
+        for (int j = 0; j < KS / 4; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<LDS_PTR(u32x4)>(xw + 1024 * q + ((((lane & 7) ^ ((t0 >> 1) + 4 * q)) & 7) << 4)) = as_u32x4(xreg[4 * j + q]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                xreg[4 * j + m] = as_bf16x8(*reinterpret_cast<const LDS_PTR(u32x4)>(xr0 + ((((2 * m + hf) ^ (r >> 1)) & 7) << 4)));
+        }
+    };
+
     const int qb = g.HHD >> 5;  // blocks per q / k / v section
-    long i = i0;
+    // (tile, first block, blocks left in the range): no division inside the loop - a later segment always starts a tile at block 0
+    int tile = (int)(i0 / NB), b0 = (int)(i0 - (long)tile * NB), left = (int)(i1 - i0);
+    bool first_seg = true;
+    bool co_ready = false;  // the rotation table of this segment's first section was requested at the end of the previous segment
     __syncthreads();  // bias vector in LDS
-    while (i < i1) {  // one segment = blocks [b0, b1) of one token tile; b0, b1 even
-        const int tile = (int)(i / NB), b0 = (int)(i % NB);
-        const int b1 = (int)((long)NB - b0 < i1 - i ? NB : b0 + (i1 - i));
+    while (left > 0) {  // one segment = blocks [b0, b1) of one token tile; b0, b1 even
+        const int b1 = NB - b0 < left ? NB : b0 + left;
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+        if (LIN1_PROBE & 128) ts0 = kstamp();
         n_wave = tile * 256 + wave * 32;
         row_q = reinterpret_cast<const char *>(g.qkv) + (size_t)n_wave * stride_q;
         row_z = reinterpret_cast<const char *>(g.z) + (size_t)n_wave * stride_z - 4 * (size_t)g.HHD;  // (z column of feature f: f - 2 HHD)
         // the wave's tokens: B fragments of all k-steps (X is padded to whole tiles)
-        // Whole 128-byte lines per 8 lanes (8 rows x 128 B per instruction: 8 cache lines, where the fragment-shaped load of a k-step
-        // touches 32), then line by line through the wave's staging image into fragment order, in place: line j of every row holds the
-        // k-steps 4 j .. 4 j + 3.  Chunk c of row t sits at t 128 + 16 (c ^ ((t >> 1) & 7)): conflict-free for both accesses.
-        if (!(LIN1_PROBE & 32) || i == i0) {
-            if (LIN1_XLOAD == 0 || K > 256) {  // (K = 384 / 512: the kernel is at its register limit and the staging pass costs more than it saves: measured)
-                const u16 *xr = g.X + (size_t)(n_wave + r) * K + 8 * hf;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) xreg[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + 16 * ks));
-            } else {
-                const u16 *xr = g.X + (size_t)(n_wave + (lane >> 3)) * K + 8 * (lane & 7);
-#pragma unroll
-                for (int j = 0; j < KS / 4; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) xreg[4 * j + q] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + (size_t)(8 * q) * K + 64 * j));
-                const unsigned t0 = lane >> 3;  // row of instruction q: t0 + 8 q, (row >> 1) & 7 = ((t0 >> 1) + 4 q) & 7
-                const unsigned xw = (unsigned)(size_t)(LDS_PTR(char))(stage) + t0 * 128;
-                const unsigned xr0 = (unsigned)(size_t)(LDS_PTR(char))(stage) + r * 128;
-#pragma unroll
-                for (int j = 0; j < KS / 4; ++j) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<LDS_PTR(u32x4)>(xw + 1024 * q + ((((lane & 7) ^ ((t0 >> 1) + 4 * q)) & 7) << 4)) = as_u32x4(xreg[4 * j + q]);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        xreg[4 * j + m] = as_bf16x8(*reinterpret_cast<const LDS_PTR(u32x4)>(xr0 + ((((2 * m + hf) ^ (r >> 1)) & 7) << 4)));
-                }
-            }
-        }
+        if (first_seg) load_x(n_wave);  // (later segments: requested at the end of the previous one)
+        finish_x();
         const unsigned nn = (unsigned)min(n_wave + r, g.N - 1);
         const unsigned n1 = g.div_magic ? __umulhi(nn, g.div_magic) : nn;
         const unsigned pos = g.mod_magic ? n1 - __umulhi(n1, g.mod_magic) * (unsigned)g.pos_mod : 0u;
 
-        // first block of the segment: MFMAs only.  The vector-memory queue holds this segment's register loads behind the ring's DMA, so
-        // the counted wait does not apply: drain everything BEFORE the barrier (a wave may read a block only once every wave's pieces
-        // of it have landed)
-        wait_vmcnt<0>();
+        // first block of the segment: MFMAs only.  The activation loads sit in the vector-memory queue behind the ring's DMA requests, so the
+        // per-step counted wait does not apply here.  A later segment's loads were issued BEFORE the previous segment's last four slab stores
+        // (see the end of the loop): vmcnt(4) covers the loads and every ring request, and leaves exactly those stores in flight - their
+        // acknowledgements take ~ 10 000 cycles under this kernel's write stream and used to be waited for at every tile boundary
+        // (profiles/r03_experiments.txt).  Then the barrier: a wave may read a block only once every wave's pieces of it have landed.
+        if (LIN1_PROBE & 128) ts3 = kstamp();
+        if (first_seg) wait_vmcnt<0>();
+        else wait_vmcnt<4>();
+        if (LIN1_PROBE & 128) ts2 = kstamp();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (LIN1_PROBE & 128) {
+            ts1 = kstamp();
+            if (dbg_seg[3] > 0) { dbg_split[0] += ts3 - ts0; dbg_split[1] += ts2 - ts3; dbg_split[2] += ts1 - ts2; }
+        }
         issue(dma_blk, dma_slot);
         advance(dma_blk);
         dma_slot = next_slot(dma_slot);
         init_acc(acc0, b0);
+        if (LIN1_PROBE & 128) tp0 = kstamp();
         step(SV, I1, I1, I0, no_side);
+        if (LIN1_PROBE & 128) tp1 = kstamp();
         // the segment's first fused step (e = b0, even): nothing to flush yet
         const int e_end = b1 - 1;
         if (b0 < 2 * qb) {
-            load_co(b0 < qb ? g.rope_q : g.rope_k, pos);
+            if (!co_ready) load_co(b0 < qb ? g.rope_q : g.rope_k, pos);
             post = b0 < qb ? g.q_premul : 1.0f;
             fused(SQK, I0, I0, I0, b0);
         } else if (b0 < 3 * qb) {
@@ -501,7 +556,26 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
             const int lo = max(b0 + 1, 3 * qb), hi = min(e_end, NB);
             if (lo < hi) run(SMLP, lo, hi);
         }
-        // last block of the segment (odd): epilogue only, then its slab
+        // last block of the segment (odd): epilogue only, then its slab.  The activation registers are free from here on: the NEXT segment's
+        // rows are requested first, so that they are older than the slab's stores (which the next segment then does not wait for).  These four
+        // stores are ordinary (compiler-visible) stores: hipcc then knows they are younger than the loads and waits with vmcnt(4), not vmcnt(0),
+        // where it consumes the loaded registers.
+        if (LIN1_PROBE & 128) tp2 = kstamp();
+        const int left_next = left - (b1 - b0);
+        co_ready = false;
+        if (left_next > 0) {  // (uniform) the next segment: tile + 1 from block 0, i.e. the q section
+            asm volatile("" ::: "memory");
+            const int nw = (tile + 1) * 256 + wave * 32;
+            load_x(nw);
+            if (b1 - 1 >= 2 * qb) {  // the drain below is not a q / k block: co is free for the next segment's q table
+                const unsigned nn2 = (unsigned)min(nw + r, g.N - 1);
+                const unsigned m1 = g.div_magic ? __umulhi(nn2, g.div_magic) : nn2;
+                load_co(g.rope_q, g.mod_magic ? m1 - __umulhi(m1, g.mod_magic) * (unsigned)g.pos_mod : 0u);
+                co_ready = true;
+            }
+            asm volatile("" ::: "memory");
+        }
+        if (LIN1_PROBE & 128) tp3 = kstamp();
         {
             const int e = b1 - 1;
             if (e < 2 * qb) {
@@ -514,15 +588,32 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
             flush_setup(e - 1);
             u32x4 pk[2];
             flush_read(0, pk);
-            flush_store(0, pk);
+            flush_store_visible(0, pk);
             flush_read(1, pk);
-            flush_store(1, pk);
+            flush_store_visible(1, pk);
         }
-        i += b1 - b0;
+        left = left_next;
+        tile += 1;
+        b0 = 0;
+        first_seg = false;
+        if (LIN1_PROBE & 128) {
+            const unsigned long long tp4 = kstamp();
+            if (dbg_seg[3] > 0) { dbg_ph[0] += tp1 - tp0; dbg_ph[1] += tp2 - tp1; dbg_ph[2] += tp3 - tp2; dbg_ph[3] += tp4 - tp3; }
+            dbg_seg[3] += 1;
+        }
     }
     wait_vmcnt<0>();  // the ring's run-ahead requests must not land in LDS after the workgroup has gone
     if ((LIN1_PROBE & 128) && lane == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) g.dbg[((size_t)blockIdx.x * 8 + wave) * 4 + k] = dbg_sum[k];
+        unsigned long long c1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+        unsigned long long *x = g.dbg + (size_t)gridDim.x * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 10;
+        x[0] = c1 - dbg_c0; x[1] = r1 - dbg_r0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[2 + k] = dbg_seg[k];
+        x[2] = dbg_split[0]; x[3] = dbg_split[1]; x[4] = dbg_split[2];  // (replaces the coarser sums)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[6 + k] = dbg_ph[k];
     }
 }

@@ -7,7 +7,7 @@ the MFMAs whose registers they overwrite), and the token-stationary linear1 kern
 from inline asm, where hipcc pads nothing.  The rules below are checked over the disassembly of every kernel:
 
   R1  no vector-memory register load (global_load / buffer_load / scratch_load / flat_load) writes a register that was the C/D operand of
-      an MFMA issued fewer than `mfma_load_gap` (12) instructions earlier (straight-line order).  LDS reads in that position are counted
+      an MFMA issued fewer than `mfma_load_gap` (12) instructions earlier in the same branch-free run of instructions.  LDS reads in that position are counted
       but not failed: hipcc places ds_read directly behind an MFMA that read the same registers as its C operand in every MFMA kernel
       of this library (its hazard recognizer pads the wait states that pattern needs); the unexplained k_resident nondeterminism came and
       went with the distance of GLOBAL loads.
@@ -130,6 +130,10 @@ def scan(name: str, insts, mfma_load_gap: int) -> Report:
         op = i.op
         if op.startswith("scratch_"):
             r.scratch += 1
+        if op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")):
+            # the listing is in layout order, not execution order: behind a branch the next instruction belongs to another path (hipcc's
+            # structurizer puts never-fallen-through "Flow" blocks between a loop body and its successor).  R1 is a straight-line rule.
+            recent_mfma = []
         if op.startswith("v_mfma") or op.startswith("v_smfmac"):
             r.n_mfma += 1
             cd = regs(i.operands[0]) | (regs(i.operands[3]) if len(i.operands) > 3 else set())

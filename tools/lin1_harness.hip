@@ -78,8 +78,8 @@ void run_case(int N, int D, int H, int mlp_ratio, int iters, int grid_new, int p
     const int grid_old = tiles < 256 ? tiles : 256;
     // ---- new kernel ----
     unsigned long long *dbg;
-    CK(hipMalloc(&dbg, 256 * 8 * 4 * 8));
-    CK(hipMemset(dbg, 0, 256 * 8 * 4 * 8));
+    CK(hipMalloc(&dbg, 256 * 8 * 14 * 8));
+    CK(hipMemset(dbg, 0, 256 * 8 * 14 * 8));
     Lin1Args la{W, X, b, rq, rk, qkv1, z1, F, N, HHD, M, pdiv, pmod, magic_of(pdiv), magic_of(pmod), inv_hd, premul, 1, dbg};
     auto knew = k_linear1_ts<HDP, K>;
     const size_t lds_new = Lin1Cfg<HDP, K>::lds_bytes(F);
@@ -124,6 +124,15 @@ void run_case(int N, int D, int H, int mlp_ratio, int iters, int grid_new, int p
     {
         std::vector<unsigned long long> hd(256 * 8 * 4);
         CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> hc(256 * 8 * 10);
+        CK(hipMemcpy(hc.data(), dbg + (size_t)gnew * 8 * 4, hc.size() * 8, hipMemcpyDeviceToHost));
+        for (int wg : {0, 100, 255})
+            for (int w : {0, 4}) {
+                const unsigned long long *c = &hc[((size_t)wg * 8 + w) * 10];
+                if (c[1]) printf("  wg %3d wave %d: kernel %.0f core cycles in %.1f us -> %.0f MHz; %llu segments; later ones: older ops done %.0f, activation loads done +%.0f, barrier +%.0f cycles\n", wg, w,
+                                 (double)c[0], c[1] / 100.0, (double)c[0] / (c[1] / 100.0), c[5], c[5] > 1 ? (double)c[2] / (c[5] - 1) : 0.0, c[5] > 1 ? (double)c[3] / (c[5] - 1) : 0.0, c[5] > 1 ? (double)c[4] / (c[5] - 1) : 0.0);
+                if (c[5] > 1) printf("       per later segment: compute-only step %.0f, fused steps %.0f, next segment's requests %.0f, drain + flush %.0f cycles\n", (double)c[6] / (c[5] - 1), (double)c[7] / (c[5] - 1), (double)c[8] / (c[5] - 1), (double)c[9] / (c[5] - 1));
+            }
         for (int wg : {0, 1, 100, 255})
             for (int w : {0, 3, 4, 7}) {
                 const unsigned long long *d = &hd[((size_t)wg * 8 + w) * 4];
