@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     // per instruction, 15 000 cycles for a workgroup's 256: measured), then - finish_x - line by line through the wave's staging image into
     // fragment order, in place: line j of every row holds the k-steps 4 j .. 4 j + 3; chunk c of row t sits at t 128 + 16 (c ^ ((t >> 1) & 7)),
     // conflict-free for both accesses.
-    constexpr bool XLINES = LIN1_XLOAD != 0 && (K <= 384 || LIN1_XLOAD == 2);  // (K = 512: 7 more spilled registers for - 1.7 %: not taken)
+    constexpr bool XLINES = LIN1_XLOAD != 0 && (K <= 384 || LIN1_XLOAD >= 2);  // (K = 512: 7 more spilled registers for - 1.7 %: not taken)
     auto load_x = [&](int nw) __attribute__((always_inline)) {
         if (!XLINES) {
             const u16 *xr = g.X + (size_t)(nw + r) * K + 8 * hf;

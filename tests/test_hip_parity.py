@@ -254,6 +254,26 @@ def test_batch_independence_and_chunking_bit_exact(dev):
     assert torch.isfinite(full).all()
 
 
+def test_pass_size_rule_equal_passes_under_the_token_cap(dev):
+    """lsl_pass_size: a pass holds at most 256 Ki tokens, and a batch that needs several passes is cut into EQUAL ones (1024 trajectories of
+    640 tokens: 342 + 342 + 340, not 409 + 409 + 206 - the short pass fills the chip worse); results do not depend on it (test above)."""
+    from lam_slide_amd import _lib
+    from oracle import latent_net
+    sh = latent_net.NetShape(depth=1, in_dim=8, hidden_size=64, num_heads=4, mlp_ratio=2)
+    net = build_net(sh, latent_net.random_params(sh, seed=1), dev)
+    net.ensure_packed(dev)
+    lib = _lib.load()
+    ps = lambda B, T, L: lib.lsl_pass_size(net._handle, B, T, L)
+    assert ps(32, 30, 256) == 32                     # the headline batch: one pass (245 760 tokens)
+    assert ps(1024, 20, 8) == 1024                   # NBA: 163 840 tokens, one pass
+    assert ps(1024, 80, 8) == 342                    # 640 tokens each: cap 409 -> three equal passes
+    assert ps(35, 30, 256) == 18                     # cap 34 -> two passes of 18 + 17
+    assert ps(3, 1000, 300) == 1                     # one trajectory above the cap still runs, alone
+    for B, T, L in ((1024, 80, 8), (35, 30, 256), (1000, 7, 100)):
+        c = ps(B, T, L)
+        assert c * T * L <= 262144 and -(-B // c) == -(-B // (262144 // (T * L)))  # same number of passes as the plain cap would give
+
+
 def test_device_noise_stream(dev):
     """Philox noise: reproducible, independent of how the batch is sharded (elem_offset), N(0,1) moments."""
     from lam_slide_amd import CreateTransport, Sampler
