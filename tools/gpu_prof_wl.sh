@@ -13,5 +13,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $B >
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $B > $out/pmc_write.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_summary.py $out/trace $out/pmc_sq2 $out/pmc_fetch $out/pmc_write > gpurun_out/prof_$tag.summary.txt 2>&1
-tail -n 2 $out/trace.log | tail -n 1 > gpurun_out/prof_$tag.bench.json
+grep "^{" $out/trace.log | tail -n 1 > gpurun_out/prof_$tag.bench.json
 find $out -name "*.csv" -size +2M -delete
