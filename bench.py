@@ -277,7 +277,7 @@ def run_rank(args) -> int:
         else f"sampled trajectories/sec ({args.workload})",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "dtype_detail": "bf16 MFMA operands (linear1, linear2, attention), fp32 accumulators / residual state / small GEMMs",
+        "build": None if stub else lib.lsl_build_info().decode(), "dtype": "bf16", "dtype_detail": "bf16 MFMA operands (linear1, linear2, attention), fp32 accumulators / residual state / small GEMMs",
         "data": "stub (launcher test, not a measurement)" if stub else "synthetic (seeded random weights and latents)",
         "config": {"workload": args.workload, "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
                    "mlp_ratio": kw["mlp_ratio"], "sampler": method, "state_updates": n_evals, "batch_per_gpu": B,

@@ -120,6 +120,9 @@ typedef struct lsl_step_ex {
 } lsl_step_ex;
 
 int lsl_version(void);
+/* Compiler and target the library was built with ("clang <version> gfx950"): the kernels' register budgets and hand-placed waits are checked
+ * against ONE compiler's code generation (tests/test_isa_scan.py); bench.py records the string next to its numbers. */
+const char *lsl_build_info(void);
 const char *lsl_last_error(void);
 
 /* LatentSIV3.__init__ counterpart: validates the shape (-> ValueError in the Python wrapper). */

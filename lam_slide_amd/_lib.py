@@ -18,7 +18,7 @@ SRC_DIR = os.path.join(_HERE, "csrc")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTED = (
-    "lsl_version", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
+    "lsl_version", "lsl_build_info", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
     "lsl_model_set_chunk", "lsl_pass_size", "lsl_sampler_path", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_sample_ex", "lsl_debug_block", "lsl_debug_taps", "lsl_debug_mods",
     "lsl_profile_enable", "lsl_profile_read", "lsl_randn",
     "lsl_decoder_create", "lsl_decoder_destroy", "lsl_decode_workspace_bytes", "lsl_decode",
@@ -115,6 +115,7 @@ def load() -> C.CDLL:
                            "(the HIP extension is the only compute path of lam_slide_amd)")
     lib = C.CDLL(LIB_PATH)
     lib.lsl_version.restype = C.c_int
+    lib.lsl_build_info.restype = C.c_char_p
     lib.lsl_last_error.restype = C.c_char_p
     lib.lsl_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]
     lib.lsl_model_set_weights.argtypes = [C.c_void_p, C.POINTER(Weights)]

@@ -933,6 +933,7 @@ int check_call(const lsl_model *m, const lsl_io *io, size_t ws_bytes, void *ws, 
 extern "C" {
 
 int lsl_version(void) { return LSL_VERSION; }
+const char *lsl_build_info(void) { return "clang " __clang_version__ " gfx950"; }
 const char *lsl_last_error(void) { return g_err; }
 
 int lsl_model_create(const lsl_model_desc *desc, lsl_model **out) try {
