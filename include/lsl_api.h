@@ -26,8 +26,13 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these entry points are its whole export list */
+#endif
 
-#define LSL_VERSION 1
+/* 2: lsl_sample_ex takes n_trace; linear1 biases are read in whole 256-feature tiles (b1 zero-padded to a multiple of 256 floats);
+ *    lsl_sample_ex, lsl_debug_taps, lsl_build_info exist. */
+#define LSL_VERSION 2
 
 typedef struct lsl_model lsl_model;
 
@@ -155,11 +160,12 @@ int lsl_forward(lsl_model *m, const lsl_io *io, void *workspace, size_t workspac
  * steps >= n_noise must have aw == 0.  noise == NULL: steps with aw != 0 draw on the device
  * (Philox4x32-10 keyed by seed, counter = (step, global element index + elem_offset); elem_offset makes
  * sharded runs reproduce the unsharded stream).
- * trace: optional device [n_steps, B*T*L*C] receiving the state after every step, or NULL. */
+ * trace: optional device [n_trace, B*T*L*C]: a record with trace_index k >= 0 writes the state after it to slice k (k < n_trace is
+ * checked; -1 = not recorded; anything below -1 is rejected), or NULL (every trace_index is then ignored). */
 int lsl_sample_ex(lsl_model *m, const lsl_io *io, const lsl_step_ex *steps, int32_t n_steps,
-                  const float *noise, int32_t n_noise, uint64_t seed, uint64_t elem_offset, float *trace,
+                  const float *noise, int32_t n_noise, uint64_t seed, uint64_t elem_offset, float *trace, int32_t n_trace,
                   void *workspace, size_t workspace_bytes, void *stream);
-/* The same with plain records: record s uses noise slice / stream step s and writes trace slice s. */
+/* The same with plain records: record s uses noise slice / stream step s and writes trace slice s (trace: [n_steps, B*T*L*C] or NULL). */
 int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_steps,
                const float *noise, int32_t n_noise, uint64_t seed, uint64_t elem_offset, float *trace,
                void *workspace, size_t workspace_bytes, void *stream);
@@ -273,6 +279,9 @@ size_t lsl_encode_workspace_bytes(const lsl_encoder *e, int32_t frames, int32_t 
 int lsl_encode(lsl_encoder *e, const float *x, const int64_t *entities, const unsigned char *mask, int32_t frames, int32_t A, float *out,
                void *workspace, size_t workspace_bytes, void *stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

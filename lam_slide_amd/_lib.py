@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, "liblamslide_hip.so")
 SRC_DIR = os.path.join(_HERE, "csrc")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
+ABI_VERSION = 2  # LSL_VERSION of include/lsl_api.h this binding was written against
+
 EXPORTED = (
     "lsl_version", "lsl_build_info", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
     "lsl_model_set_chunk", "lsl_pass_size", "lsl_sampler_path", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_sample_ex", "lsl_debug_block", "lsl_debug_taps", "lsl_debug_mods",
@@ -91,8 +93,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", LIB_PATH, os.path.join(SRC_DIR, "lsl_api.hip")]
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value",
+           "-Wl,--version-script=" + os.path.join(SRC_DIR, "exports.map"), "-o", LIB_PATH, os.path.join(SRC_DIR, "lsl_api.hip")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))
@@ -130,7 +132,7 @@ def load() -> C.CDLL:
     lib.lsl_sample.argtypes = [C.c_void_p, C.POINTER(IO), C.POINTER(Step), C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64,
                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_sample_ex.argtypes = [C.c_void_p, C.POINTER(IO), C.POINTER(StepEx), C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64,
-                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_debug_block.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lsl_debug_taps.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
@@ -154,8 +156,9 @@ def load() -> C.CDLL:
     lib.lsl_encode_workspace_bytes.restype = C.c_size_t
     lib.lsl_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.c_void_p]
-    if lib.lsl_version() != 1:
-        raise RuntimeError("liblamslide_hip.so version mismatch")
+    if lib.lsl_version() != ABI_VERSION:
+        raise RuntimeError(f"liblamslide_hip.so reports ABI version {lib.lsl_version()}, this package binds version {ABI_VERSION}: rebuild it "
+                           "(python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
 

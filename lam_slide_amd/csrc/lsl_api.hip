@@ -20,6 +20,7 @@
 #include "k_attn.hip.h"
 #include "k_gemm.hip.h"
 #include "k_lin1.hip.h"
+#include "k_lin2.hip.h"
 #include "k_small.hip.h"
 #include "k_resident.hip.h"
 #ifdef LSL_EXPERIMENTS  // measured-and-rejected GEMM structures, built only by tools/build_experiments.sh (never in the product library)
@@ -102,8 +103,13 @@ struct Workspace {
     float *cond_emb, *h, *yemb, *tfeat, *hid, *vec, *mods;
     float *saved;  // [n][C] state kept by an LSL_STEP_SAVE record of lsl_sample_ex (Heun's x_hat)
     u16 *a, *qkv, *z;
+    u16 *w2p;  // linear2 weights of every sub-block in the fragment order of k_linear2_ws (k_lin2_pack, once per call), or NULL
     size_t bytes;
 };
+
+int env_int(const char *name, int dflt);
+int tune_int(const char *name, int dflt);
+bool linear2_ws_shape_ok(int D, int K2);
 
 // Scratch layout for a pass over `bc` trajectories.
 Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
@@ -132,12 +138,11 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.a = (u16 *)take(n_pad * D * 2);
     ws.qkv = (u16 *)take(n_pad * 3 * m->HHD * 2);  // (padded like a / z: the token-stationary linear1 stores whole 256-token tiles)
     ws.z = (u16 *)take(n_pad * m->K2 * 2);
+    ws.w2p = linear2_ws_shape_ok((int)D, m->K2) ? (u16 *)take((size_t)2 * d.depth * D * m->K2 * 2) : nullptr;
     ws.bytes = off;
     return ws;
 }
 
-int env_int(const char *name, int dflt);
-int tune_int(const char *name, int dflt);
 // Two lanes (opt-in, LSL_LANES=2): the passes of a large batch alternate between the caller's stream and a second one, so that one
 // half-batch's memory-bound kernels (LayerNorm, attention, output head: a quarter of the step) and the tails of its persistent GEMM launches
 // share the chip with the other half's kernels: +1.4 % on the cfg-2 bench (profiles/r03_experiments.txt).  Only when each half still
@@ -441,6 +446,41 @@ void launch_linear1_ts(int hdp, int D, const Lin1Args &a, hipStream_t st) {
     }
 }
 
+// linear2 + gated residual update on the weight-stationary kernel (k_lin2.hip.h): F a multiple of 128, K2 one of the instantiated widths
+// (K2 / 8 stationary registers per wave: 2 048, peptide, does not fit).  Same bits as the tile kernels (tools/lin2_harness.hip), so the
+// choice may depend on the launch.  LSL_LIN2_WS=0 (read in the product too: the GPU suite compares the two paths bit for bit) turns it off.
+bool linear2_ws_shape_ok(int D, int K2) {
+    static const int on = env_int("LSL_LIN2_WS", 1);
+    return on && D % 128 == 0 && D <= 512 && (K2 == 1536 || K2 == 1280 || K2 == 768 || K2 == 384);
+}
+template <int K, int NCH, int NS>
+bool launch_linear2_ws_t(Lin2Args a, int shared, hipStream_t st) {
+    using C = Lin2Cfg<K, NCH, NS, true>;
+    auto kern = k_linear2_ws<K, NCH, NS, true>;
+    // grid = 8 x slices x rpx workgroups, at most one per CU; fewer token ranges than 32-token blocks
+    const int slices = a.F / 128, cus = device_cus(), NBLK = (a.N + 31) / 32;
+    int rpx = std::max(1, cus / (8 * slices));
+    while (rpx > 1 && 8 * rpx > NBLK) --rpx;
+    const int ranges = 8 * rpx, max_blocks = (NBLK + ranges - 1) / ranges + 1;
+    const int gate_rows = shared ? 1 : (max_blocks * 32 + a.tpt - 1) / a.tpt + 1;  // trajectories one range can span
+    if (gate_rows > C::max_gate_rows) return false;
+    a.slices = slices;
+    a.rpx = rpx;
+    a.gate_rows = gate_rows;
+    LSL_ALLOW_LDS(kern, (size_t)163840);
+    hipLaunchKernelGGL(kern, dim3(8 * slices * rpx), dim3(512), C::lds_bytes(gate_rows), st, a);
+    return true;
+}
+bool launch_linear2_ws(int K2, const Lin2Args &a, int shared, hipStream_t st) {
+    switch (K2) {
+        case 1536: return launch_linear2_ws_t<1536, 3, 3>(a, shared, st);
+        case 1280: return launch_linear2_ws_t<1280, 5, 5>(a, shared, st);
+        case 768: return launch_linear2_ws_t<768, 3, 3>(a, shared, st);
+        case 384: return launch_linear2_ws_t<384, 3, 3>(a, shared, st);
+        default: return false;
+    }
+}
+
 // GEMM tiling (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
 //   (features x tokens, waves, BK x ring stages):
 //   5  256x256  8 waves 64x2, one tile per workgroup
@@ -653,6 +693,11 @@ int run_yemb(lsl_model *m, const Workspace &ws, const float *y, int rows, hipStr
 
 void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream_t st) {
     const int half = m->d.head_dim_pad / 2;
+    if (ws.w2p) {  // linear2 weights in MFMA-fragment order (k_linear2_ws keeps them in registers for a whole launch: every load 1 KiB contiguous)
+        const size_t per = (size_t)m->d.hidden * m->K2;
+        for (int bi = 0; bi < 2 * m->d.depth; ++bi)
+            hipLaunchKernelGGL(k_lin2_pack, dim3(128), dim3(256), 0, st, ws.w2p + (size_t)bi * per, (const u16 *)m->blocks[bi].w2, m->d.hidden, m->K2);
+    }
     hipLaunchKernelGGL(k_rope_table, dim3((L * half + 255) / 256), dim3(256), 0, st, ws.rope_l, L, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
     hipLaunchKernelGGL(k_rope_table, dim3((T * half + 255) / 256), dim3(256), 0, st, ws.rope_t, T, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
     // the same tables with each attention block's query / key norm scales folded in (spatial blocks: L positions, temporal: T)
@@ -740,9 +785,16 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     if ((unsigned long long)n * (unsigned)(T * L) >= (1ull << 32)) return fail(-3, "pass too large for the trajectory arithmetic");
     const bool fuse = fuse_next && bi + 1 < 2 * d.depth && linear2_can_fuse_ln(D, n, m->K2);
     const float *nbase = mods + (size_t)((bi + 1) / 2) * 6 * D + (((bi + 1) & 1) ? 3 * D : 0);  // next sub-block: shift, scale
-    EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L, 0, magic_of(T * L), fuse ? ws.a : nullptr, nbase, nbase + D};
-    launch_gemm((const u16 *)bw.w2, ws.z, D, n, m->K2, e2, st, 32, fuse);
-    if (a_written) *a_written = fuse;
+    bool on_ws = false;
+    if (ws.w2p && !fuse && (unsigned long long)n * (unsigned)(4 * D) < (1ull << 32)) {  // (32-bit byte offsets into h)
+        const Lin2Args l2{ws.w2p + (size_t)bi * D * m->K2, ws.z, bw.b2, mbase + 2 * D, h, D, n, mod_stride, T * L, magic_of(T * L), 1, 0, 0, 0, nullptr};
+        on_ws = launch_linear2_ws(m->K2, l2, mod_stride == 0, st);
+    }
+    if (!on_ws) {
+        EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L, 0, magic_of(T * L), fuse ? ws.a : nullptr, nbase, nbase + D};
+        launch_gemm((const u16 *)bw.w2, ws.z, D, n, m->K2, e2, st, 32, fuse);
+    }
+    if (a_written) *a_written = fuse && !on_ws;
     m->prof.end(1, st);
     LSL_CHECK_LAUNCH("block");
     return 0;
@@ -1115,7 +1167,7 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
     if (!steps || n_steps <= 0) return fail(-3, "steps required");
     std::vector<lsl_step_ex> ex((size_t)n_steps);
     for (int s = 0; s < n_steps; ++s) ex[s] = lsl_step_ex{steps[s].t, steps[s].ax, steps[s].am, steps[s].aw, 0.0f, 0, s, s};
-    return lsl_sample_ex(m, io, ex.data(), n_steps, noise, n_noise, seed, elem_offset, trace, workspace, workspace_bytes, stream);
+    return lsl_sample_ex(m, io, ex.data(), n_steps, noise, n_noise, seed, elem_offset, trace, n_steps, workspace, workspace_bytes, stream);
 } catch (const std::bad_alloc &) {
     return fail(-5, "out of host memory");
 } catch (...) {
@@ -1123,7 +1175,7 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
 }
 
 int lsl_sample_ex(lsl_model *m, const lsl_io *io, const lsl_step_ex *steps, int32_t n_steps, const float *noise, int32_t n_noise, uint64_t seed,
-                  uint64_t elem_offset, float *trace, void *workspace, size_t workspace_bytes, void *stream) try {
+                  uint64_t elem_offset, float *trace, int32_t n_trace, void *workspace, size_t workspace_bytes, void *stream) try {
     DeviceGuard dev_guard_((hipStream_t)stream);
     int chunk = 0;
     if (int rc = check_call(m, io, workspace_bytes, workspace, &chunk)) return rc;
@@ -1133,7 +1185,8 @@ int lsl_sample_ex(lsl_model *m, const lsl_io *io, const lsl_step_ex *steps, int3
         const lsl_step_ex &sp = steps[s];
         if (sp.aw != 0.0f && (sp.noise_index < 0 || (noise && sp.noise_index >= n_noise)))
             return fail(-3, "step %d needs noise slice %d but only %d slices were given", s, sp.noise_index, n_noise);
-        if (sp.trace_index >= n_steps) return fail(-3, "step %d: trace slice %d out of range", s, sp.trace_index);
+        if (sp.trace_index < -1 || (trace && sp.trace_index >= n_trace))
+            return fail(-3, "step %d: trace slice %d out of range (the trace buffer holds %d slices)", s, sp.trace_index, trace ? n_trace : 0);
         if (sp.as != 0.0f && !have_saved) return fail(-3, "step %d reads the saved state before any record saved one", s);
         have_saved |= (sp.flags & LSL_STEP_SAVE) != 0;
         plain &= sp.as == 0.0f && sp.flags == 0 && sp.noise_index == s && sp.trace_index == s;

@@ -528,10 +528,12 @@ class Sampler:
                 if nz.shape[0] < need or tuple(nz.shape[1:]) != tuple(x.shape):
                     raise ValueError(f"noise must be [>={need}, {tuple(x.shape)}], got {tuple(nz.shape)}")
             stream = torch.cuda.current_stream(dev).cuda_stream
-            fn_ = lib.lsl_sample if records is None else lib.lsl_sample_ex
-            _lib.check(fn_(net._handle, C.byref(io), arr, len(arr), nz.data_ptr() if nz is not None else None,
-                           nz.shape[0] if nz is not None else 0, call_seed, self.elem_offset,
-                           trace.data_ptr() if trace is not None else None, ws.data_ptr(), ws.numel(), stream))
+            head = (net._handle, C.byref(io), arr, len(arr), nz.data_ptr() if nz is not None else None,
+                    nz.shape[0] if nz is not None else 0, call_seed, self.elem_offset, trace.data_ptr() if trace is not None else None)
+            if records is None:
+                _lib.check(lib.lsl_sample(*head, ws.data_ptr(), ws.numel(), stream))
+            else:  # (the library checks every record's trace slice against the slices the buffer really has)
+                _lib.check(lib.lsl_sample_ex(*head, trace.shape[0] if trace is not None else 0, ws.data_ptr(), ws.numel(), stream))
         net.last_path = "hip"
         self.last_path = "fused"
         # (extended records always run the general kernels: the trajectory-resident kernel implements the plain affine step only)

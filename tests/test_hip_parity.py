@@ -39,7 +39,7 @@ def build_net(sh, params, dev):
 def test_library_loaded_and_fails_loudly_on_cpu(dev):
     from lam_slide_amd import LatentSIV3, _lib
     lib = _lib.load()
-    assert lib.lsl_version() == 1
+    assert lib.lsl_version() == _lib.ABI_VERSION == 2
     net = LatentSIV3(depth=1, in_dim=8, hidden_size=64, num_heads=4, reset_parameters=False)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 2, 3, 8), torch.zeros(1), torch.zeros(1, 2, 3, 8), torch.zeros(1, 2, 3, dtype=torch.long))
@@ -587,6 +587,40 @@ def test_graph_replay_matches_eager_bits(dev):
         os.remove(path)
     assert torch.equal(res["0"], res["2"])
     assert not torch.equal(res["0"][0], res["0"][1])
+
+
+def test_kernel_choice_knobs_do_not_change_bits(dev):
+    """The knobs that pick between bit-identical kernel paths, exercised at the headline shape (T = 30, L = 256, D = 512: linear2 on the
+    weight-stationary kernel k_linear2_ws, 18 trajectories = 138 240 tokens so that LSL_LANES=2 really splits the batch over two
+    streams): LSL_LIN2_WS=0 (linear2 back on the 256 x 256-tile kernel) and LSL_LANES=2 must reproduce the default run's bits.  The
+    knobs are read once per process, so every arm runs in a subprocess."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from lam_slide_amd import CreateTransport, SecondStageSampler\n"
+        "from oracle import latent_net\n"
+        "from test_hip_parity import build_net\n"
+        "dev = torch.device('cuda:0')\n"
+        "sh = latent_net.NetShape(depth=1, in_dim=32, hidden_size=512, num_heads=16, mlp_ratio=2)\n"
+        "net = build_net(sh, latent_net.random_params(sh, seed=11), dev)\n"
+        "drv = SecondStageSampler(net, CreateTransport('GVP', 'data')(), cond_idx=(0, 10), sampling_kwargs={'sampling_method': 'euler', 'num_steps': 3})\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "lat = torch.randn(18, 30, 256, 32, generator=g).to(dev); init = torch.randn(18, 30, 256, 32, generator=g).to(dev)\n"
+        "torch.save(drv.sample_latents(lat, init=init).cpu(), sys.argv[1])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, extra in (("default", {}), ("tile_linear2", {"LSL_LIN2_WS": "0"}), ("two_lanes", {"LSL_LANES": "2"})):
+        path = f"/tmp/lsl_knob_{name}_{os.getpid()}.pt"
+        env = {k: v for k, v in os.environ.items() if k not in ("LSL_LIN2_WS", "LSL_LANES")}
+        env.update(extra)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=900)
+        res[name] = torch.load(path)
+        os.remove(path)
+    assert torch.isfinite(res["default"]).all()
+    assert torch.equal(res["default"], res["tile_linear2"])
+    assert torch.equal(res["default"], res["two_lanes"])
 
 
 def _hip_taps(net, lib, bi, h_in, mods, B, T, L, dev):

@@ -24,6 +24,12 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_lib.EXPORTED), declared ^ set(_lib.EXPORTED)
     for s in declared:
         assert hasattr(lib, s), s
+    assert re.search(r"#define LSL_VERSION (\d+)", header).group(1) == str(_lib.ABI_VERSION)
+    # built with -fvisibility=hidden: the dynamic symbol table defines the entry points of the header and nothing else (no device stubs,
+    # no C++ helpers)
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = {line.split()[-1] for line in nm.splitlines() if line.split()[-2:-1] and line.split()[-2] in "TDBRWV"}
+    assert defined == declared, defined ^ declared
 
 
 def test_model_create_validation_without_gpu():
