@@ -9,7 +9,7 @@ random weights of that architecture, random conditioning latents) and resident i
 region.
 
 Multi-GPU (``--gpus N``): one process per GPU, the batch is sharded (weak scaling: per-GPU batch fixed), no
-data-path collective, one all_gather (RCCL over xGMI, backend "nccl") of the final latents per step inside the
+data-path collective, one gather onto rank 0 (RCCL over xGMI, backend "nccl") of the final latents per step inside the
 timed region.  Launched by ``torch.distributed.run`` the ranks are taken from the environment; invoked plainly
 (``python bench.py --gpus 8``) the script starts its N ranks itself as child processes BEFORE any GPU call and
 relays rank 0's single JSON line.  Documented weak-scaling lines beside the headline:
@@ -69,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--chunk", type=int, default=0, help="trajectories per pass inside the library (0 = default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch and stage-1 legs")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event passes (rocprofv3 runs: every launch of the trace then belongs to a warm-up or timed sampling call)")
     ap.add_argument("--profile-kernel", type=int, default=0, help="kernel class timed with HIP events (lsl_api.h)")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed passes: per-kernel-class time shares")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="gloo only with --stub-compute (launcher test on CPU)")
@@ -224,12 +225,17 @@ def run_rank(args) -> int:
         def sync():
             torch.cuda.synchronize()
 
-    gather = [torch.empty_like(init) for _ in range(world)] if world > 1 else None
+    # the one collective of the path: the final latents of every rank's trajectories are gathered on rank 0 (RCCL over xGMI with backend
+    # "nccl"); no rank needs the others' results, so nothing is broadcast back
+    gather = [torch.empty_like(init) for _ in range(world)] if world > 1 and rank == 0 else None
+
+    def gather_final(final):
+        dist.gather(final.contiguous(), gather, dst=0)
 
     def one_step():
         final = sample_call()
         if world > 1:
-            dist.all_gather(gather, final.contiguous())
+            gather_final(final)
         return final
 
     def fence():
@@ -254,15 +260,20 @@ def run_rank(args) -> int:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-        # the one collective of the path, timed on its own (outside the timed region above): RCCL all_gather of the final latents
+        # the one collective of the path, timed on its own (outside the timed region above): RCCL gather of the final latents
         fence()
         tg = time.perf_counter()
         for _ in range(5):
-            dist.all_gather(gather, final.contiguous())
+            gather_final(final)
         fence()
         gather_ms = (time.perf_counter() - tg) / 5 * 1e3
     assert torch.isfinite(final).all()
-    rccl_ranks = dist.get_world_size() if world > 1 else 1
+    rccl_ranks = 1
+    if world > 1:  # counted by the collective itself: a rank that silently fell out of the group cannot be reported
+        ones = torch.ones(1, device=dev, dtype=torch.int32)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
 
     if rank != 0:
         if world > 1:
@@ -281,7 +292,7 @@ def run_rank(args) -> int:
         "data": "stub (launcher test, not a measurement)" if stub else "synthetic (seeded random weights and latents)",
         "config": {"workload": args.workload, "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
                    "mlp_ratio": kw["mlp_ratio"], "sampler": method, "state_updates": n_evals, "batch_per_gpu": B,
-                   "global_batch": B * world, "parallelism": f"batch-shard x{world}, 1 all_gather/step",
+                   "global_batch": B * world, "parallelism": f"batch-shard x{world}, 1 gather to rank 0 per step",
                    # rank r draws the device noise of global elements [r * stride, (r + 1) * stride): the slice of the unsharded stream
                    "noise_elem_stride_per_rank": B * T * L * kw["in_dim"]},
         "rccl_ranks": rccl_ranks, "collective_backend": args.backend if world > 1 else None, "gather_ms": gather_ms,
@@ -307,7 +318,7 @@ def run_rank(args) -> int:
         lib.lsl_profile_enable(net._handle, -1, 0)
         return tm.value, ln.value
 
-    if not resident:
+    if not resident and not args.no_roofline:
         total_ms.value, launches.value = profiled_pass(args.profile_kernel)
     out["config"]["kernels"] = "trajectory-resident (k_resident)" if resident else "general"
     f_eval = flops_per_eval_per_traj(kw, T, L)
@@ -325,9 +336,13 @@ def run_rank(args) -> int:
     lin1_ts = D in (128, 256, 384, 512) and (kw["num_heads"] * hdp) % 64 == 0 and M % 64 == 0
     lin1_name = ("k_linear1_ts (token-stationary linear1 + bias/QK-norm/RoPE/GELU epilogue)" if lin1_ts
                  else "k_gemm_glds<EpiLinear1> (linear1 + QK-norm/RoPE/GELU epilogue)")
+    K2 = kw["num_heads"] * hdp + M
+    lin2_ws = D % 128 == 0 and D <= 512 and K2 in (1536, 1280, 768, 384) and os.environ.get("LSL_LIN2_WS", "1") != "0"
+    lin2_name = ("k_linear2_ws (weight-stationary linear2 + gate/residual epilogue)" if lin2_ws
+                 else "k_gemm_glds<EpiLinear2> (linear2 + gate/residual epilogue)")
     kinfo = {
         0: (lin1_name, 2.0 * tok_total * D * (3 * D + M) * block_evals),
-        1: ("k_gemm_glds<EpiLinear2> (linear2 + gate/residual epilogue)", 2.0 * tok_total * (D + M) * D * block_evals),
+        1: (lin2_name, 2.0 * tok_total * (D + M) * D * block_evals),
         2: ("k_attention", 4.0 * tok_total * D * (L + T) / 2 * block_evals),
     }
     kname, kflops_total = kinfo.get(args.profile_kernel, (f"kernel class {args.profile_kernel}", 0.0))
@@ -365,7 +380,30 @@ def run_rank(args) -> int:
         "whole_path_tflops": value * f_eval * n_evals / 1e12,
         "whole_path_frac": value * f_eval * n_evals / 1e12 / PEAK_BF16_DENSE_TFLOPS,
     }
-    if not resident and args.profile_kernel == 0:  # the second GEMM of the block beside it
+    if args.no_roofline:
+        out["roofline"] = None
+    # The whole step against the HBM roof.  Bytes = the HBM-side traffic of every kernel of one step (2 * FETCH_SIZE + WRITE_SIZE from the
+    # committed rocprofv3 PMC passes, derived by tools/traffic_from_pmc.py), which scales with the tokens of a step (weights are < 1 %), so
+    # the per-token figure is scaled to this run's batch; time = this run's measured step.  As the step is cut into kernels, its HBM floor
+    # is ABOVE its MFMA floor: the decomposition, not any single kernel, is HBM-bound.
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(tf))
+            if tj.get("workload") != args.workload or "step" not in tj:
+                continue
+            step_bytes = tj["step"]["bytes_per_token"] * tok_total
+            step_flops = float(f_eval) * n_evals * B
+            out["roofline_step"] = {
+                "bound": "hbm", "achieved": step_bytes / (step_ms * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
+                "frac": step_bytes / (step_ms * 1e-3) / 8e12, "frac_of_copy_rate": step_bytes / (step_ms * 1e-3) / 6.29e12,
+                "bytes_per_step": step_bytes, "bytes_per_token_per_step": tj["step"]["bytes_per_token"],
+                "hbm_floor_ms": step_bytes / 8e12 * 1e3, "hbm_floor_ms_at_copy_rate": step_bytes / 6.29e12 * 1e3,
+                "mfma_floor_ms": step_flops / (PEAK_BF16_DENSE_TFLOPS * 1e12) * 1e3, "ms_per_step": step_ms,
+                "traffic_source": os.path.relpath(tf, ROOT), "derived_by": "tools/traffic_from_pmc.py (not measured in this run: PMC counters need rocprofv3)"}
+            break
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    if not resident and args.profile_kernel == 0 and not args.no_roofline:  # the second GEMM of the block beside it
         ms2, ln2 = profiled_pass(1)
         avg2 = ms2 / max(1, ln2)
         fl2 = kinfo[1][1] / max(1, launches_total)
@@ -402,11 +440,16 @@ def run_rank(args) -> int:
     if world == 1 and not args.no_extras:
         # the same call at small batches (SURVEY 8d asks B = 1 and 8 beside the throughput batch)
         small = {}
-        for b in (1, 8):
-            if b >= B:
+        for b in (1, 8, 64):  # (B = 1, 8 and 64 beside the throughput batch)
+            if b == B:
                 continue
-            mkb = {k: v[:b] for k, v in mk.items()}
-            sec = timed_call(lambda: fn(init[:b], net.forward, **mkb)[-1], reps=2)
+            if b < B:
+                initb, mkb = init[:b], {k: v[:b] for k, v in mk.items()}
+            else:  # a larger batch than the headline's: the same trajectories repeated (throughput does not depend on the values)
+                rep = -(-b // B)
+                initb = init.repeat(rep, 1, 1, 1)[:b]
+                mkb = {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:b] for k, v in mk.items()}
+            sec = timed_call(lambda: fn(initb, net.forward, **mkb)[-1], reps=2)
             small[f"B{b}"] = {"value": b / sec, "unit": "trajectories/s", "ms_per_call": sec * 1e3}
         out["gpu_small_batch"] = small
         # the steps either side of the loop, on the device, for the batch of one step (frozen stage-1 models of the MD17 shape)

@@ -1,6 +1,6 @@
 """Caller-side harness of the sampling path: counterpart of ``SecondStageCondLightningBase.
 {setup_conditioning, prepare_batch, sample}`` (lightning_base.py:205-263) without Lightning, plus the
-multi-GPU sharding of independent trajectories (one process per GPU, one RCCL all_gather at the end).
+multi-GPU sharding of independent trajectories (one process per GPU, one RCCL gather onto rank 0 at the end).
 
 The frozen stage-1 encoder / decoder are NOT reimplemented here: ``encode`` / ``decode`` are callables
 supplied by the caller (the reference's own first-stage model), exactly as the reference composes them.
@@ -147,11 +147,13 @@ class SecondStageSampler:
 
 
 @torch.no_grad()
-def sample_sharded(sample_fn: Callable[[Tensor, int], Tensor], latents: Tensor, group=None) -> Tensor:
+def sample_sharded(sample_fn: Callable[[Tensor, int], Tensor], latents: Tensor, group=None, dst: Optional[int] = 0) -> Optional[Tensor]:
     """Trajectories are independent end to end (no op mixes batch elements), so the batch is split
-    contiguously over the ranks with no collective on the data path; one all_gather of the final latents
-    closes the job.  ``sample_fn(local_latents, first_global_index) -> local_final``.  Every rank gets the
-    full result in the original order.  With backend "nccl" the gather is RCCL over xGMI."""
+    contiguously over the ranks with no collective on the data path; ONE gather of the final latents onto rank
+    ``dst`` closes the job (BASELINE north_star: "a single RCCL gather over xGMI at the end"; with backend "nccl" it
+    is RCCL).  ``sample_fn(local_latents, first_global_index) -> local_final``.  Rank ``dst`` returns the full result in
+    the original order, every other rank ``None`` - nobody needs the other shards back, and a gather moves 1 / world
+    of what an all_gather does.  ``dst=None``: every rank gets the full result (an all_gather)."""
     if not (dist.is_available() and dist.is_initialized()):
         return sample_fn(latents, 0)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -161,11 +163,17 @@ def sample_sharded(sample_fn: Callable[[Tensor, int], Tensor], latents: Tensor, 
     # has to stay on the same call number as the unsharded run)
     local = sample_fn(latents[lo:hi], lo)
     sizes = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
-    cap = max(sizes)
+    cap = max(sizes)  # (shards differ by at most one trajectory: the collective moves equal-sized buffers)
     pad = local.new_zeros((cap,) + tuple(latents.shape[1:]))
     pad[: hi - lo] = local
-    gathered = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(gathered, pad.contiguous(), group=group)
+    if dst is None:
+        gathered = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(gathered, pad.contiguous(), group=group)
+    else:
+        gathered = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad.contiguous(), gathered, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+        if rank != dst:
+            return None
     return torch.cat([g[:s] for g, s in zip(gathered, sizes)], dim=0)
 
 

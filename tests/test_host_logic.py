@@ -199,16 +199,21 @@ init = torch.randn(5, 4, 6, 8, generator=g)
 def local(l, lo):
     xc, m = harness.setup_conditioning(l, (0, 2), True)
     return harness.sample_latents(p, sh, otr.Transport("GVP", "data"), init[lo:lo + l.shape[0]], xc, m, None, "ODE", {"sampling_method": "euler", "num_steps": 4})
-out = sample_sharded(local, lat)
+out = sample_sharded(local, lat)            # one gather onto rank 0: only rank 0 holds the result
 full = local(lat, 0)
-assert out.shape == full.shape and torch.allclose(out, full, atol=1e-6), float((out - full).abs().max())
+if int(os.environ["RANK"]) == 0:
+    assert out.shape == full.shape and torch.allclose(out, full, atol=1e-6), float((out - full).abs().max())
+else:
+    assert out is None
+every = sample_sharded(local, lat, dst=None)  # all_gather form: every rank
+assert every.shape == full.shape and torch.allclose(every, full, atol=1e-6)
 dist.destroy_process_group()
 print("rank", os.environ["RANK"], "ok")
 """
 
 
 def test_two_rank_sharding_over_gloo(tmp_path):
-    """N>1 path on CPU: contiguous batch split, no data-path collective, one all_gather; the CPU oracle
+    """N>1 path on CPU: contiguous batch split, no data-path collective, one gather onto rank 0 (or an all_gather on request); the CPU oracle
     stands in for the per-rank compute (checker role only)."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)

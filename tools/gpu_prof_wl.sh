@@ -6,7 +6,7 @@ tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-extras $*"
+B="$GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-extras --no-roofline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $B > $out/trace.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc_sq2 -- python3 $B > $out/pmc_sq2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $B > $out/pmc_fetch.log 2>&1
