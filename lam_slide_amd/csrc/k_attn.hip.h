@@ -12,6 +12,8 @@
 // so every per-query quantity lives on the query's own lane.  q arrives pre-multiplied by
 // hd^-0.5 * log2(e) (linear1 epilogue), so probabilities are exp2(s - max).
 #pragma once
+#include <type_traits>
+
 #include "common.hip.h"
 
 struct AttnArgs {
@@ -26,6 +28,8 @@ struct AttnArgs {
     int hd;          // true head_dim (<= HDP).  hd < HDP (peptide: 24 of 32): the padding channels of v are zero, and k_attention_rows
                      // turns channel hd of the staged V into ones, so that row hd of O^T = V^T P^T IS the softmax denominator
     int bound;       // k_attention_rows: 1 = softmax shifted by the Cauchy-Schwarz bound |q| max|k| instead of the row maximum when that is safe
+    int planes, npad;    // k_attention_stream (HDP = 32, spatial): 1 = q / k / v are head-major planes qkv[section][head][npad tokens][32] (k_lin1.hip.h)
+    const float *kmax2;  // k_attention_stream: device scalar, an upper bound of |k_j|^2 for every key of this block (head_dim max_d ks_d^2: k_rope_scaled)
 };
 
 template <int HDP>
@@ -338,6 +342,259 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Streaming form of k_attention_rows for the axes of the large configurations (round 4).  Measured on k_attention_rows at cfg 2
+// (profiles/r03_rocprof_summary.txt): waves are parked at s_waitcnt / the staging barrier for 52 % of their lifetime - 15 360 (spatial) or
+// 32 768 (temporal) short-lived workgroups each wait for their own K / V rows from HBM before they can start, and five resident
+// workgroups per CU do not cover that.  Here a PERSISTENT 8-wave workgroup (two per CU) walks the units u = v, v + grid, ... and the rows
+// of its next unit arrive by LDS-DMA (per-lane source addresses apply the read-side swizzle) in the second of two K | V images while the
+// current unit is computed; each wave's next query tile arrives the same way in a wave-private 32-row image.  One barrier per unit.
+//   unit (LONG: 128 < S <= 256)  = one (sequence, head): K / V images of 256 rows, wave w owns query tile w;
+//   unit (SHORT: 8 < S <= 32)    = 8 consecutive heads of one sequence: 8 images of 32 rows, wave w owns head w of the group.
+// Softmax without a maximum and without a shift: |s_ij| <= |q_i| |k_j| <= |q_i| sqrt(kmax2) =: m_i with kmax2 = head_dim max_d ks_d^2 >=
+// |k_j|^2 for every key of the block (k = RMS-normalised x scale, rotated: AttnArgs::kmax2, written by k_rope_scaled) - a bound that needs
+// neither a max pass nor the staged keys.  While m_i <= 60, exp2(s_ij) itself fits fp32 / bf16 and the common factor cancels in O / l; a
+// query tile with a larger bound takes the exact max pass (k_attention_rows has the argument).  Row sums by the all-ones MFMA.
+// Memory-pipe lessons built in (profiles/r04_experiments.txt): vector-memory operations complete in issue order, so whatever a wave
+// issues in front of its next requests delays them - the output therefore leaves as 16-byte-per-lane row pieces through the (by then
+// free) query image, with plain stores (8-byte stores from the accumulator layout: 32 partial writes per instruction; streaming stores
+// 3 x slower); q / k / v of spatial sub-blocks come as head-major planes (AttnArgs::planes), where a unit's rows are one contiguous run -
+// as token-major rows every 64-byte row piece drags a whole 128-byte line through the L1 miss path; units are dealt round-robin in
+// XCD-contiguous order so that heads sharing lines meet in one L2.
+template <int HDP, bool LONG>
+__global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = HDP * 2, CPR = ROWB / 16, KS = HDP / 16;
+    constexpr int KVB = 256 * ROWB, BUF = 2 * KVB;  // K (or V) image of a unit; K | V
+    constexpr int NI = BUF / 1024, IPW = NI / 8;    // LDS-DMA instructions per unit / per wave
+    constexpr int RPI = 1024 / ROWB;                // image rows per instruction
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hf = lane >> 5;
+    const int S = a.S, nkt = LONG ? (S + 31) >> 5 : 1;
+    const int hgroups = a.H >> 3;
+    const long n_units = LONG ? (long)a.n_seq * a.H : (long)a.n_seq * hgroups;
+    // units are dealt round-robin over the workgroups in XCD-contiguous order: neighbouring (sequence, head) units - whose 64-byte row pieces
+    // share 128-byte lines - run at the same time on one XCD and meet in its L2 (with a contiguous range per workgroup the second head of a
+    // line came one unit-time later, after the line had left the L2: FETCH_SIZE 1.38 GB per launch for 0.755 GB of rows)
+    const long ustep = gridDim.x, u0 = xcd_remap(blockIdx.x, gridDim.x), u1 = n_units;
+    if (u0 >= u1) return;  // (uniform)
+    const bool has_tile = !LONG || wave < nkt;  // (uniform) LONG: wave w = query tile w
+    const unsigned rs = 3u * a.HHD;
+    const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))(smem);
+    const bool planes = LONG && HDP == 32 && a.planes;  // (uniform) plane layout: positions of a sequence are consecutive tokens (pos_stride 1)
+
+    // per-lane parts of the addresses (constant over the units)
+    unsigned voff_kv[IPW];
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+        const int i = wave * IPW + k, kv = i / (NI / 2), ii = i % (NI / 2);
+        const int R = RPI * ii + lane / CPR, slot = lane % CPR;
+        const int chunk = kv == 0 ? slot ^ (HDP == 32 ? (R >> 2) & 3 : (R >> 3) & 1) : slot;
+        const int item_local = LONG ? 0 : R >> 5, pos = min(LONG ? R : R & 31, S - 1);
+        voff_kv[k] = planes ? 2u * (((unsigned)(1 + kv) * a.H * a.npad + (unsigned)pos) * HDP + chunk * 8)
+                            : 2u * ((unsigned)pos * a.pos_stride * rs + (1 + kv) * a.HHD + item_local * HDP + chunk * 8);
+    }
+
+    auto unit_tok0 = [&](long u, int &head0) __attribute__((always_inline)) {
+        const int seq = LONG ? (int)(u / a.H) : (int)(u / hgroups);
+        head0 = LONG ? (int)(u % a.H) : 8 * (int)(u % hgroups);
+        return (size_t)(seq / a.inner) * a.outer_stride + (seq % a.inner);
+    };
+    // (wave-uniform by construction; the readfirstlanes make it provable for the "s" operands of the asm statements)
+    auto uni_ptr = [](const char *q) __attribute__((always_inline)) {
+        const unsigned long long v = (unsigned long long)q;
+        const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const char *>(((unsigned long long)hi32 << 32) | lo32);
+    };
+    // The query tile of a wave's next unit arrives by LDS-DMA as well, in a WAVE-PRIVATE 32-row image (swizzled like K): only this wave
+    // reads it, so it is single-buffered and needs no barrier - the wave requests the next tile once its own reads of the current one have
+    // returned.  (Asm loads into registers were tried first: hipcc copied the destination registers of the in-flight loads at the loop's
+    // back-edge and in front of the wait - NaNs; and once accumulator registers are named in asm it allocates the same ones itself.)
+    constexpr int QIMG = 32 * ROWB, QPW = QIMG / 1024 > 0 ? QIMG / 1024 : 1;  // bytes and LDS-DMA instructions of a query tile
+    char *const qimg = smem + 2 * BUF + wave * QIMG;
+    unsigned voff_qt[QPW];
+#pragma unroll
+    for (int k = 0; k < QPW; ++k) {
+        const int R = RPI * k + lane / CPR, slot = lane % CPR;  // tile row, 16-byte slot
+        const int chunk = slot ^ (HDP == 32 ? (R >> 2) & 3 : (R >> 3) & 1);
+        const int pos = min((LONG ? 32 * wave : 0) + R, S - 1);
+        voff_qt[k] = planes ? 2u * ((unsigned)pos * HDP + chunk * 8) : 2u * ((unsigned)pos * a.pos_stride * rs + (LONG ? 0 : wave * HDP) + chunk * 8);
+    }
+    auto request = [&](long u, int SET) __attribute__((always_inline)) {  // SET: K | V image of the unit being requested
+        int head0;
+        const size_t tok0 = unit_tok0(u, head0);
+        const char *base = uni_ptr(reinterpret_cast<const char *>(a.qkv) +
+                                   (planes ? 2 * (((size_t)head0 * a.npad + tok0) * HDP) : 2 * (tok0 * rs + (size_t)head0 * HDP)));
+#pragma unroll
+        for (int k = 0; k < IPW; ++k) {
+            const int i = wave * IPW + k;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + SET * BUF + (i / (NI / 2)) * KVB + (i % (NI / 2)) * 1024);
+            const unsigned vk = voff_kv[k];
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vk), "s"(base), "s"(dst) : "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < QPW; ++k) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + 2 * BUF + wave * QIMG + k * 1024);
+            const unsigned vq = voff_qt[k];  // (an odr-use: a generic lambda does not capture a variable that only appears as an asm operand)
+            if (QIMG >= 1024 || lane < QIMG / 16)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vq), "s"(base), "s"(dst) : "memory");
+        }
+    };
+
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, grp = lane >> 4;
+    const int v_off = (4 * (grp >> 1) + gq) * ROWB + ((HDP == 32 ? (grp & 1) * 16 : 0) + 4 * gp) * 2;
+    const int krow0 = LONG ? 0 : 32 * wave;  // first image row of this wave's keys
+    const bool ragged = (S & 31) != 0;       // (uniform) the last key tile is partial
+    const int last_rows = S - 32 * (nkt - 1);
+    f32x16 zero;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero[e] = 0.0f;
+    const float kmax2 = a.kmax2 ? *a.kmax2 : 0.0f;
+
+    // Output: a wave's tile O^T (32 queries on the lanes, HDP channels on the accumulator rows) goes through the wave's query image - free
+    // once the NEXT unit's query tile has been read into registers - and leaves as whole row pieces, 16 bytes per lane (HDP = 32: 16 rows x
+    // 64 B per instruction).  Stored straight from the accumulator layout (8 bytes per lane, 32 partial 16-byte writes per instruction) the
+    // stores clog the in-order vector-memory pipe in front of the next unit's requests: measured 0.78 ms per launch with streaming stores,
+    // 0.27 with plain ones, 0.205 with no store at all (profiles/r04_experiments.txt).
+    constexpr int OPW = QPW;  // output store instructions per wave and unit
+    unsigned voff_zr[OPW];
+    bool zr_ok[OPW];
+#pragma unroll
+    for (int k = 0; k < OPW; ++k) {
+        const int R = RPI * k + lane / CPR, chunk = lane % CPR;
+        const int pos = (LONG ? 32 * wave : 0) + R;
+        zr_ok[k] = pos < S && (QIMG >= 1024 || lane < QIMG / 16);
+        voff_zr[k] = 2u * ((unsigned)min(pos, S - 1) * a.pos_stride * a.zw + (LONG ? 0 : wave * HDP) + chunk * 8);
+    }
+    auto read_q = [&](bf16x8 (&q)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) q[s2] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qimg + k_swz<HDP>(r, 2 * s2 + hf)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in registers before anything else is written to the image
+    };
+    request(u0, 0);
+    wait_vmcnt<0>();
+    bf16x8 qn[KS];
+    read_q(qn);
+    int buf = 0;
+    for (long u = u0; u < u1; u += ustep) {
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) qf[s2] = qn[s2];
+        __builtin_amdgcn_s_barrier();  // every wave's rows of this unit have landed (each waited for its own); every wave has left the other image
+        asm volatile("" ::: "memory");
+        const bool more = u + ustep < u1;  // (uniform)
+        if (more) request(u + ustep, buf ^ 1);
+        f32x16 o = zero;
+        float inv_l = 0.0f;
+        if (has_tile) {
+            const char *Ks = smem + buf * BUF, *Vs = Ks + KVB;
+            auto scores = [&](int kt, const f32x16 &init) __attribute__((always_inline)) {
+                f32x16 t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(krow0 + kt * 32 + r, hf))), qf[0], init);
+                if (KS == 2)
+                    t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(krow0 + kt * 32 + r, 2 + hf))), qf[KS - 1], t);
+                if (kt == nkt - 1 && ragged) {  // wave-uniform; only the last tile can hold clamped rows past the sequence: they do not take part
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (acc_row(e, hf) >= last_rows) t[e] = -INFINITY;
+                }
+                return t;
+            };
+            float mx = -INFINITY;
+            bool shifted = false;
+            if (a.kmax2) {
+                float qq = 0.0f;
+#pragma unroll
+                for (int s2 = 0; s2 < KS; ++s2) {
+                    const u32x4 w = __builtin_bit_cast(u32x4, qf[s2]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+                        qq = fmaf(lo, lo, fmaf(hi, hi, qq));
+                    }
+                }
+                qq += xhalf(qq);
+                const float m = sqrtf(qq * kmax2) * 1.02f;
+                shifted = __ballot(m > 60.0f) == 0;  // (wave-uniform)
+                if (shifted) mx = m;
+            }
+            if (!shifted) {
+                for (int kt = 0; kt < nkt; ++kt) {
+                    const f32x16 t = scores(kt, zero);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[e]);
+                }
+                mx = fmaxf(mx, xhalf(mx));
+            }
+            // Shifted by the bound (the usual case): NO shift is applied at all.  |s_ij| <= m_i <= 60, so exp2(s_ij) lies in [2^-60, 2^60]: it
+            // fits fp32 and bf16 (8 exponent bits) as it is, the sums over <= 256 keys stay below 2^68, and the common factor 2^m_i cancels in
+            // O / l exactly as a shift would.  The score MFMA then starts from the constant 0 (an inline operand) instead of a 16-register
+            // preset that hipcc copies into the accumulator in front of every tile (16 of the 60 vector instructions per tile pair that the
+            // counters showed).  Exact-maximum fallback: the preset form.
+            f32x16 negmx;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) negmx[e] = shifted ? 0.0f : -mx;
+            const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // eight bf16 1.0
+            f32x16 lsum = zero;
+            auto tile = [&](int kt, const f32x16 &t) __attribute__((always_inline)) {
+                float p[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(t[e]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 pw = {pack2(p[8 * s2], p[8 * s2 + 1]), pack2(p[8 * s2 + 2], p[8 * s2 + 3]),
+                                pack2(p[8 * s2 + 4], p[8 * s2 + 5]), pack2(p[8 * s2 + 6], p[8 * s2 + 7])};
+                    const char *vb = Vs + (krow0 + kt * 32 + 16 * s2) * ROWB + v_off;
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb));
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb + 8 * ROWB));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o = mfma32(__builtin_bit_cast(bf16x8, vv), as_bf16x8(pw), o);
+                    lsum = mfma32(as_bf16x8(ones_w), as_bf16x8(pw), lsum);  // every row = sum over this tile's keys, column = query
+                }
+            };
+            if (shifted) {
+                if (!LONG) tile(0, scores(0, zero));
+                else {
+#pragma unroll 2
+                    for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, zero));  // (fully unrolled, hipcc hoists every fragment address and spills)
+                }
+            } else {
+                for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, negmx));
+            }
+            inv_l = 1.0f / lsum[0];
+        }
+        wait_vmcnt<0>();  // the next unit's rows and query tile (requested a whole unit ago)
+        asm volatile("" ::: "memory");
+        if (more) read_q(qn);
+        if (has_tile) {
+            // O^T -> the query image, rows = queries: lane (query r, half hf) writes channels 8 q4 + 4 hf .. + 3 (8 bytes) into the 16-byte slot of
+            // chunk q4; then row-wise, 16 bytes per lane
+#pragma unroll
+            for (int q4 = 0; q4 < HDP / 8; ++q4) {
+                const u32x2 pk = {pack2(o[4 * q4] * inv_l, o[4 * q4 + 1] * inv_l), pack2(o[4 * q4 + 2] * inv_l, o[4 * q4 + 3] * inv_l)};
+                *reinterpret_cast<u32x2 *>(qimg + k_swz<HDP>(r, q4) + 8 * hf) = pk;
+            }
+            int head0;
+            const size_t tok0 = unit_tok0(u, head0);
+            const char *zb = uni_ptr(reinterpret_cast<const char *>(a.z) + 2 * (tok0 * a.zw + (size_t)head0 * HDP));
+#pragma unroll
+            for (int k = 0; k < OPW; ++k) {
+                const int R = RPI * k + lane / CPR;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(qimg + k_swz<HDP>(R, lane % CPR));
+                const unsigned vz = voff_zr[k];
+                if (zr_ok[k]) {
+                    if (a.nt) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(vz), "v"(v), "s"(zb) : "memory");
+                    else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vz), "v"(v), "s"(zb) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image has been read before the next query tile is requested into it
+        }
+        buf ^= 1;
+    }
+    wait_vmcnt<0>();
 }
 
 // ---------------------------------------------------------------------------------------------------

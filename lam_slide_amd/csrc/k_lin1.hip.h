@@ -43,6 +43,9 @@ struct Lin1Args {
     int nt;                         // streaming stores
     unsigned long long *dbg;        // timing-probe builds only (LIN1_PROBE & 128): per workgroup and wave, 4 cycle sums; else unused
     int wpt;                        // 0: the (tile, block) sequence is cut evenly over the grid; > 0: wpt workgroups per token tile, grid = wpt x tiles
+    int planes;                     // HDP = 32 only: 1 = q / k / v leave as head-major planes qkv[section][head][npad tokens][32] (a (sequence, head)'s rows are
+                                    // then contiguous: k_attention_stream's spatial units), 0 = token-major rows qkv[token][3 HHD]
+    int npad;                       // tokens rounded up to 256 (the plane pitch)
 };
 
 template <int HDP, int K>
@@ -230,16 +233,23 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     // instruction (32-bit per-lane offsets against a uniform base: both output buffers are far below 4 GiB per pass); two halves of 2
     // instructions each, so that a fused step can place them inside its MFMA chain.  Per segment: the wave's first row in both buffers.
     const char *row_q = nullptr, *row_z = nullptr;
-    const unsigned stride_q = 2u * 3 * g.HHD, stride_z = 2u * (g.HHD + g.M);
-    const unsigned voff_q = (lane >> 3) * stride_q + 16 * (lane & 7), voff_z = (lane >> 3) * stride_z + 16 * (lane & 7);
+    // q / k / v as head-major planes (Lin1Args::planes, 32-wide heads): block b IS plane b (section x head); a token row of a plane is 64
+    // bytes, and of the slab's row-wise lanes (row lane >> 3, chunk c = lane & 7) those with c >= 4 belong to the next plane: the same
+    // flush with other constants - 8 rows x 64 B contiguous per plane and instruction
+    const bool planes = HDP == 32 && g.planes;  // (uniform)
+    const unsigned plane_bytes = 64u * (unsigned)g.npad;
+    const unsigned stride_q = planes ? 64u : 2u * 3 * g.HHD, stride_z = 2u * (g.HHD + g.M);
+    const unsigned blk_q = planes ? plane_bytes : 64u;  // bytes between the q / k / v destinations of consecutive blocks
+    const unsigned voff_q = planes ? ((lane >> 2) & 1) * (plane_bytes - 64u) + (lane >> 3) * 64 + 16 * (lane & 7) : (lane >> 3) * stride_q + 16 * (lane & 7);
+    const unsigned voff_z = (lane >> 3) * stride_z + 16 * (lane & 7);
     const int slab_z = 3 * (g.HHD >> 5);  // first block that goes to z (uniform; sections start on multiples of 64 features)
     const char *fl_base = nullptr;
     unsigned fl_stride8 = 0, fl_voff = 0;
     auto flush_setup = [&](int b_even) __attribute__((always_inline)) {
         const bool to_qkv = b_even < slab_z;
-        fl_base = (to_qkv ? row_q : row_z) + 64 * b_even;
+        fl_base = to_qkv ? row_q : row_z;
         fl_stride8 = 8 * (to_qkv ? stride_q : stride_z);
-        fl_voff = to_qkv ? voff_q : voff_z;
+        fl_voff = to_qkv ? voff_q + blk_q * (unsigned)b_even : voff_z + 64u * (unsigned)b_even;  // (32-bit: a pass's q / k / v and z stay below 4 GiB)
     };
     auto flush_read = [&](int half, u32x4 (&pk)[2]) __attribute__((always_inline)) {
 #pragma unroll

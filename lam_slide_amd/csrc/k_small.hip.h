@@ -29,11 +29,18 @@ struct RopeScaledJobs {
     float4 *out[16];
     const float *scale[16];
     int n_pos[16];
+    float *sq_bound[16];  // or NULL: receives head_dim * max_d scale_d^2, an upper bound of the squared norm of every vector this table scales
+                          // (RMS-normalised over head_dim, times scale, rotated: k_attention_stream's softmax shift)
     int n_jobs;
 };
 __global__ void k_rope_scaled(RopeScaledJobs jobs, int hd, int hdp, float theta) {
     const int job = blockIdx.y;
     if (job >= jobs.n_jobs) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && jobs.sq_bound[job]) {
+        float mx = 0.0f;
+        for (int d = 0; d < hd; ++d) mx = fmaxf(mx, jobs.scale[job][d] * jobs.scale[job][d]);
+        *jobs.sq_bound[job] = mx * (float)hd;
+    }
     const int half = hdp / 2, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= jobs.n_pos[job] * half) return;
     const int p = i / half, j = i % half;
@@ -46,6 +53,15 @@ __global__ void k_rope_scaled(RopeScaledJobs jobs, int hd, int hdp, float theta)
     }
     const float s0 = jobs.scale[job][2 * j], s1 = jobs.scale[job][2 * j + 1];
     jobs.out[job][i] = make_float4(c * s0, sn * s1, sn * s0, c * s1);
+}
+
+// q / k / v planes [3 H][npad][32] (Lin1Args::planes) -> token-major rows [n][3 H 32]: lsl_debug_taps hands the taps out in one layout
+__global__ void k_planes_to_rows(u16 *rows, const u16 *planes, int n, int npad, int heads3) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
+    if (i >= (long)n * heads3 * 4) return;
+    const int c = (int)(i & 3), p = (int)((i >> 2) % heads3);
+    const long tok = (i >> 2) / heads3;
+    *reinterpret_cast<u32x4 *>(rows + (tok * heads3 + p) * 32 + 8 * c) = *reinterpret_cast<const u32x4 *>(planes + ((long)p * npad + tok) * 32 + 8 * c);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -103,6 +103,7 @@ struct Workspace {
     float *cond_emb, *h, *yemb, *tfeat, *hid, *vec, *mods;
     float *saved;  // [n][C] state kept by an LSL_STEP_SAVE record of lsl_sample_ex (Heun's x_hat)
     u16 *a, *qkv, *z;
+    float *kmax2;  // [2 * depth]: bound of |k|^2 per attention block (k_rope_scaled), for k_attention_stream's softmax shift
     u16 *w2p;  // linear2 weights of every sub-block in the fragment order of k_linear2_ws (k_lin2_pack, once per call), or NULL
     size_t bytes;
 };
@@ -126,6 +127,7 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.rope_t = (float2 *)take((size_t)T * (d.head_dim_pad / 2) * sizeof(float2));
     ws.rope_qk_stride = (size_t)std::max(T, L) * (d.head_dim_pad / 2);
     ws.rope_qk = (float4 *)take((size_t)4 * d.depth * ws.rope_qk_stride * sizeof(float4));
+    ws.kmax2 = (float *)take((size_t)2 * d.depth * sizeof(float));
     ws.cond_emb = (float *)take(n * D * 4);
     ws.h = (float *)take(n * D * 4);
     ws.yemb = (float *)take((size_t)bc * D * 4);
@@ -588,8 +590,45 @@ void launch_attention_rows(const AttnArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)((items + ITEMS - 1) / ITEMS)), dim3(NW * 64), lds, st, a);
 }
 
+// persistent, double-buffered form (k_attention_stream): axes of 129 .. 256 positions (one (sequence, head) per unit) and of 9 .. 32 positions
+// with a multiple of 8 heads (8 heads of a sequence per unit).  The choice depends on the model and on T, L only - never on the batch - so a
+// trajectory's bits are the same in any batch.  LSL_ATTN_STREAM=0 (read in the product too: A/B runs) keeps k_attention_rows.
+int attention_stream_mode(int S, int H) {  // 0: k_attention_rows / tiny / online, 1: stream SHORT, 2: stream LONG
+    static const int on = env_int("LSL_ATTN_STREAM", 1);
+    if (!on) return 0;
+    if (S > 128 && S <= 256) return 2;
+    if (S > 8 && S <= 32 && H % 8 == 0) return 1;
+    return 0;
+}
+// q / k / v as head-major planes (k_lin1.hip.h, Lin1Args::planes): spatial sub-blocks (positions = consecutive tokens) whose attention
+// runs the LONG stream kernel, 32-wide heads, token-stationary linear1.  LSL_QKV_PLANES=0 keeps token-major rows (A/B runs).
+bool qkv_planes_ok(int hdp, int hidden, int heads, int S, bool temporal, bool lin1_ts) {
+    static const int on = env_int("LSL_QKV_PLANES", 1);
+    return on && hdp == 32 && hidden == 512 && !temporal && lin1_ts && heads % 2 == 0 && attention_stream_mode(S, heads) == 2;
+}
+template <int HDP>
+bool launch_attention_stream(const AttnArgs &a, hipStream_t st) {
+    const int mode = attention_stream_mode(a.S, a.H);
+    const bool is_long = mode == 2;
+    if (!mode || !a.kmax2) return false;
+    const size_t lds = (size_t)2 * 2 * 256 * HDP * 2 + (size_t)8 * 32 * HDP * 2;  // two images of K | V, 256 rows each; a 32-row query image per wave
+    const long n_units = is_long ? (long)a.n_seq * a.H : (long)a.n_seq * (a.H / 8);
+    const int grid = (int)std::min<long>(2L * device_cus(), n_units);  // two workgroups per CU (2 x 80 KiB of LDS at 32-wide heads)
+    // plain stores: behind streaming stores the in-order vector-memory queue reports the next unit's requests late (measured: 0.78 vs 0.27 ms)
+    AttnArgs b = a;
+    b.nt = 0;
+    auto go2 = [&](auto kern) {
+        LSL_ALLOW_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, b);
+    };
+    if (!is_long) go2(k_attention_stream<HDP, false>);
+    else go2(k_attention_stream<HDP, true>);
+    return true;
+}
+
 template <int HDP>
 void launch_attention_t(const AttnArgs &a, hipStream_t st) {
+    if (launch_attention_stream<HDP>(a, st)) return;
     const int Sp = (a.S + 31) & ~31;
     static const int online = tune_int("LSL_ATTN_ONLINE", 0);  // 1: force the online-softmax kernel (A/B measurements)
     if (!online && a.S <= 8) {  // one lane per (query, head), no MFMA padding
@@ -703,7 +742,7 @@ void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream
     // the same tables with each attention block's query / key norm scales folded in (spatial blocks: L positions, temporal: T)
     const int nb = 2 * m->d.depth;
     for (int b0 = 0; b0 < 2 * nb; b0 += 16) {
-        RopeScaledJobs jobs;
+        RopeScaledJobs jobs{};
         jobs.n_jobs = std::min(16, 2 * nb - b0);
         int max_pos = 0;
         for (int k = 0; k < jobs.n_jobs; ++k) {
@@ -711,6 +750,7 @@ void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream
             jobs.out[k] = ws.rope_qk + (size_t)t * ws.rope_qk_stride;
             jobs.scale[k] = (t & 1) ? m->blocks[bi].ks : m->blocks[bi].qs;
             jobs.n_pos[k] = (bi & 1) ? T : L;
+            jobs.sq_bound[k] = (t & 1) ? ws.kmax2 + bi : nullptr;
             max_pos = std::max(max_pos, jobs.n_pos[k]);
         }
         hipLaunchKernelGGL(k_rope_scaled, dim3((max_pos * half + 255) / 256, jobs.n_jobs), dim3(256), 0, st, jobs, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
@@ -739,10 +779,13 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     const int pdiv = temporal ? L : 1, pmod = temporal ? T : L;
     auto magic_of = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };
     if ((unsigned long long)n * (unsigned)std::max(pdiv, pmod) >= (1ull << 32)) return fail(-3, "pass too large for the position arithmetic");
-    if (linear1_ts_ok(d.head_dim_pad, D, m->F1, m->HHD, n)) {
+    const bool lin1_ts = linear1_ts_ok(d.head_dim_pad, D, m->F1, m->HHD, n);
+    const int npad = (n + 255) & ~255;
+    const bool planes = qkv_planes_ok(d.head_dim_pad, D, d.heads, temporal ? T : L, temporal != 0, lin1_ts);
+    if (lin1_ts) {
         const Lin1Args la{(const u16 *)bw.w1, ws.a, bw.b1, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                           ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->F1, n, m->HHD, d.mlp_dim,
-                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, nullptr};
+                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, nullptr, 0, planes ? 1 : 0, npad};
         launch_linear1_ts(d.head_dim_pad, D, la, st);
     } else if (d.head_dim_pad == 32) {
         EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
@@ -766,6 +809,9 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     aa.H = d.heads;
     aa.hd = d.head_dim;
     static const int attn_bound = tune_int("LSL_ATTN_BOUND", 1);
+    aa.kmax2 = ws.kmax2 + bi;
+    aa.planes = planes ? 1 : 0;
+    aa.npad = npad;
     aa.bound = attn_bound == 2 || (attn_bound == 1 && (temporal ? T : L) > 96);  // short axes: the max pass is one or two tiles, cheaper than the norms
     if (!temporal) {  // sequences (b,t), positions l
         aa.S = L; aa.n_seq = bc * T; aa.inner = 1; aa.outer_stride = L; aa.pos_stride = 1;
@@ -1397,7 +1443,13 @@ int lsl_debug_taps(lsl_model *m, int32_t bi, const float *h_in, const float *mod
     const size_t n = (size_t)B * T * L;
     hipMemcpyAsync(ws.h, h_in, n * m->d.hidden * 4, hipMemcpyDeviceToDevice, st);
     if (int rc = run_block(m, ws, bi, ws.h, mods, m->MODW, B, T, L, st, false, false, nullptr, true)) return rc;
-    hipMemcpyAsync(qkv_out, ws.qkv, n * 3 * m->HHD * 2, hipMemcpyDeviceToDevice, st);
+    const bool temporal = bi & 1;
+    if (qkv_planes_ok(m->d.head_dim_pad, m->d.hidden, m->d.heads, temporal ? T : L, temporal, linear1_ts_ok(m->d.head_dim_pad, m->d.hidden, m->F1, m->HHD, (int)n))) {
+        const long chunks = (long)n * 3 * m->d.heads * 4;  // the block left q / k / v as head-major planes: hand them out as token-major rows
+        hipLaunchKernelGGL(k_planes_to_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (u16 *)qkv_out, ws.qkv, (int)n,
+                           (int)((n + 255) & ~(size_t)255), 3 * m->d.heads);
+    } else
+        hipMemcpyAsync(qkv_out, ws.qkv, n * 3 * m->HHD * 2, hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(z_out, ws.z, n * m->K2 * 2, hipMemcpyDeviceToDevice, st);
     LSL_CHECK_LAUNCH("debug taps");
     return 0;
