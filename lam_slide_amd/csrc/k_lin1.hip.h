@@ -94,7 +94,8 @@ enum { LIN1_QK = 0, LIN1_V = 1, LIN1_MLP = 2 };
 // erf-GELU of an accumulator value: gelu_fast() (common.hip.h) with max(x, 0) as ONE v_max_f32.  Through the builtins hipcc emits two (a
 // canonicalising v_max x, x first), and the epilogue of an mlp block is bound by its vector-instruction count.  Inline asm is invisible to
 // the hazard recognizer, so this form may only read values that the matrix pipe finished writing long ago: here the accumulator tile of the
-// PREVIOUS block (hundreds of cycles).  Same value as gelu_fast for every non-NaN input.
+// PREVIOUS block (hundreds of cycles).  Same value as gelu_fast for every non-NaN input except the SIGN of a zero result (x = -0.0: v_max
+// gives +0, v_med3 keeps -0, and the bf16 packing keeps the sign bit): the two linear1 paths are bit-identical up to that.
 __device__ __forceinline__ float lin1_gelu(float x) {
     const float ax = fabsf(x);
     const float h = __builtin_amdgcn_exp2f(LSL_GELU_Q(ax));

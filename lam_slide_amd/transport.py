@@ -307,7 +307,10 @@ def _rms(v: Tensor) -> float:
 def dopri5_solve(f: Callable[[float, Tensor], Tensor], y0: Tensor, grid: Sequence[float], rtol: float, atol: float,
                  max_steps: int = 100000) -> Tuple[List[Tensor], Dict[str, int]]:
     """Solution of y' = f(t, y) at the (increasing) times `grid`, grid[0] being the initial time: [y(grid[0]), ..., y(grid[-1])] and
-    counters.  Steps are chosen by the error controller alone and run past the output times; outputs are interpolated."""
+    counters.  Steps are chosen by the error controller alone and run past the output times; outputs are interpolated.  An output time
+    that does not exceed the current time (repeated grid points, a single-point grid) returns the current state.  Time arithmetic runs in
+    Python float64 (torchdiffeq keeps t in the dtype of the state's time tensor: accepted-step sequences agree in accuracy class, not in
+    the last bit); the error ratio is one host scalar per step (`_rms` -> float: a device sync per stage combination)."""
     t0 = float(grid[0])
     f0 = f(t0, y0)
     nfe = 1
@@ -353,6 +356,9 @@ def dopri5_solve(f: Callable[[float, Tensor], Tensor], y0: Tensor, grid: Sequenc
                 dt = dt * 10.0
             else:
                 dt = dt * min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1.0 else 0.2))
+        if coeff is None or t <= t_lo:  # an output time at (or before) the current time with no accepted step to interpolate: the state itself
+            out.append(y)
+            continue
         x = (tn - t_lo) / (t - t_lo)
         e, d, c, b, a = coeff
         out.append(e + x * (d + x * (c + x * (b + x * a))))

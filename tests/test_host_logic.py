@@ -438,6 +438,11 @@ def test_dopri5_solver_against_exact_solution_and_scipy():
     ys_f, st_f = dopri5_solve(f, y0, list(np.linspace(0.0, 2.0, 201)), 1e-3, 1e-6)
     ys_c, st_c = dopri5_solve(f, y0, [0.0, 2.0], 1e-3, 1e-6)
     assert st_f["nfe"] == st_c["nfe"] and torch.allclose(ys_f[-1], ys_c[-1], rtol=0, atol=1e-12)
+    # degenerate grids: a single point, and output times that do not exceed the current time before any step was accepted
+    ys_1, _ = dopri5_solve(f, y0, [0.0], 1e-3, 1e-6)
+    assert len(ys_1) == 1 and torch.equal(ys_1[0], y0)
+    ys_r, _ = dopri5_solve(f, y0, [0.0, 0.0, 0.5, 0.5], 1e-6, 1e-9)
+    assert torch.equal(ys_r[0], y0) and torch.equal(ys_r[1], y0) and torch.allclose(ys_r[2], ys_r[3], rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("path,pred,reverse", [("GVP", "data", False), ("Linear", "velocity", False), ("VP", "noise", False)])
