@@ -17,14 +17,13 @@
 //     first half from zero and hands its 16 accumulator registers to the hi wave through 4 KiB of LDS, the hi wave continues the chain one
 //     block later (the MFMA's C input) and finishes the tile.  The pair is a two-stage pipeline, skewed by one token block;
 //   * a chunk of the LDS ring therefore holds, per token row, [KC columns of the lo half of block m | KC columns of the hi half of block
-//     m - 1]; 3 chunks per block (KC = K / 6), 3 ring slots, one workgroup barrier per chunk, filled by LDS-DMA two chunks ahead;
+//     m - 1]; NCH chunks per block (3 at K = 1 536: KC = 256), NS ring slots, one workgroup barrier per chunk, filled by LDS-DMA NS - 1
+//     chunks ahead;
 //   * the hi wave's epilogue (+ bias, gate, + residual) of tile m - 1 runs inside its MFMA chain of tile m: the residual rows arrive by
-//     LDS-DMA (no registers) a whole block earlier, the arithmetic runs in the accumulator layout against that LDS image IN PLACE, and
-//     the image leaves row-wise as whole 128-byte segments;
-//   * memory latency is decoupled from the in-order vector-memory queue: only the lo waves request (and wait for) token chunks, the hi
-//     waves own every access that can miss to HBM - the residual rows, the stores, and TOUCH loads (one dword per 128-byte line into a
-//     scratch LDS word, never waited for) that pull the token rows and residual rows of the blocks three ahead into the XCD's L2, so the
-//     chunk requests the workgroup does wait for are L2 hits.
+//     LDS-DMA (no registers) more than a block earlier, the arithmetic runs in the accumulator layout against that LDS image IN PLACE, and
+//     the image leaves row-wise as whole 128-byte segments (streaming stores);
+//   * a wave's vector-memory operations complete in issue order, so the roles are split by what may miss to HBM: only the lo waves request
+//     (and wait for) token chunks - their queue holds nothing else -, the hi waves own the residual requests and the stores.
 // Work split: grid = 8 x slices x ranges-per-XCD; the F / 128 slice workgroups of one token range sit on one XCD (block b and b + 8 share
 // one: speed only) and share the range's token rows through its L2.
 //
@@ -44,14 +43,13 @@ struct Lin2Args {
     int F, N;
     int mod_stride, tpt;  // tokens per trajectory
     unsigned tpt_magic;   // floor(2^32 / tpt) + 1 (0 when tpt == 1)
-    int nt;               // streaming stores
     int slices, rpx;      // feature slices of 128 (F / 128) and token ranges per XCD: grid = 8 * slices * rpx
     int gate_rows;        // rows of the LDS gate table (>= the trajectories one token range spans; host-checked)
     unsigned long long *dbg;  // probe builds only
 };
 
 #ifndef LIN2_PROBE
-#define LIN2_PROBE 0  // tools/lin2_harness.hip only (results wrong): 1 no epilogue arithmetic + residual traffic, 2 no MFMAs, 4 no stores, 8 no token DMA, 16 no touches, 32 no residual DMA, 128 stamps
+#define LIN2_PROBE 0  // tools/lin2_harness.hip only (results wrong): 1 no epilogue arithmetic + residual traffic, 2 no MFMAs, 4 no stores, 8 no token DMA, 32 no residual DMA, 128 cycle stamps
 #endif
 #ifndef LIN2_HI_FIRST
 #define LIN2_HI_FIRST 0  // 1: waves 0-3 (the older half, which wins the issue arbitration) finish the chains and run the epilogue

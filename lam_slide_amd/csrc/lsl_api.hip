@@ -833,7 +833,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     const float *nbase = mods + (size_t)((bi + 1) / 2) * 6 * D + (((bi + 1) & 1) ? 3 * D : 0);  // next sub-block: shift, scale
     bool on_ws = false;
     if (ws.w2p && !fuse && (unsigned long long)n * (unsigned)(4 * D) < (1ull << 32)) {  // (32-bit byte offsets into h)
-        const Lin2Args l2{ws.w2p + (size_t)bi * D * m->K2, ws.z, bw.b2, mbase + 2 * D, h, D, n, mod_stride, T * L, magic_of(T * L), 1, 0, 0, 0, nullptr};
+        const Lin2Args l2{ws.w2p + (size_t)bi * D * m->K2, ws.z, bw.b2, mbase + 2 * D, h, D, n, mod_stride, T * L, magic_of(T * L), 0, 0, 0, nullptr};
         on_ws = launch_linear2_ws(m->K2, l2, mod_stride == 0, st);
     }
     if (!on_ws) {

@@ -478,3 +478,29 @@ def test_sample_ode_reverse_asserts_like_the_reference():
     for method in ("euler", "dopri5"):
         with pytest.raises(AssertionError):
             s.sample_ode(sampling_method=method, reverse=True)
+
+
+def test_committed_traffic_file_reproduces_from_the_committed_pmc_summary(tmp_path):
+    """bench.py's `roofline_step` / `traffic` figures come from profiles/r*_traffic.json; that file must be what tools/traffic_from_pmc.py
+    derives from the committed rocprofv3 summary of the same round (no hand-edited numbers)."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    newest = [f for f in files if "step" in json.load(open(f))]
+    assert newest, "no scripted traffic file committed"
+    committed = json.load(open(newest[-1]))
+    tag = os.path.basename(newest[-1]).split("_")[0]
+    summary = os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.txt")
+    out = tmp_path / "t.json"
+    calls = {k["trace_calls"] // k["launches_per_step"] for k in committed["kernels"].values() if k["launches_per_step"] >= 50}
+    assert len(calls) == 1
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_from_pmc.py"), summary, "--workload", committed["workload"], "--batch",
+                    str(committed["batch"]), "--calls", str(calls.pop()), "--flops-per-step",
+                    str(committed["step"]["mfma_floor_ms_at_2_5_pflop_s"] * 1e-3 * 2.5e15), "-o", str(out)], check=True, capture_output=True)
+    again = json.load(open(out))
+    assert again["step"]["bytes"] == committed["step"]["bytes"]
+    assert abs(again["step"]["kernel_ms"] - committed["step"]["kernel_ms"]) < 1e-6
+    for cls in ("linear1", "linear2", "attention", "ln_modulate"):
+        assert again[cls]["bytes"] == committed[cls]["bytes"] and again[cls]["kernel"] == committed[cls]["kernel"]
+    # the decomposition's floors as DESIGN.md section 5 states them: HBM floor above the MFMA floor
+    assert committed["step"]["hbm_floor_ms_at_8_tb_s"] > committed["step"]["mfma_floor_ms_at_2_5_pflop_s"]

@@ -90,7 +90,7 @@ void run_case(int N, int F, int tpt, int shared, int iters, int rpx_arg) {
     unsigned long long *dbg;
     CK(hipMalloc(&dbg, 256 * 8 * 16 * 8));
     CK(hipMemset(dbg, 0, 256 * 8 * 16 * 8));
-    Lin2Args la{Wp, Z, b, gate, h1, F, N, mod_stride, tpt, magic_of(tpt), 1, slices, rpx, gate_rows, dbg};
+    Lin2Args la{Wp, Z, b, gate, h1, F, N, mod_stride, tpt, magic_of(tpt), slices, rpx, gate_rows, dbg};
     auto knew = k_linear2_ws<K, LIN2_NCH, LIN2_NS, LIN2_HB2 != 0>;
     const size_t lds_new = C2::lds_bytes(gate_rows);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(knew), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
