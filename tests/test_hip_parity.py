@@ -623,6 +623,51 @@ def test_kernel_choice_knobs_do_not_change_bits(dev):
     assert torch.equal(res["default"], res["two_lanes"])
 
 
+def test_attention_stream_kernel_against_rows_kernel(dev):
+    """k_attention_stream (persistent, LDS-DMA double-buffered; the large axes of every config) against k_attention_rows (LSL_ATTN_STREAM=0)
+    on the attention output of one spatial and one temporal sub-block: ragged last key tile (S = 200, 30, 9), both head widths, the
+    head-major q / k / v planes (hidden 512) and token-major rows, more and fewer units than workgroups.  The two differ only by the bf16
+    rounding of the probabilities (another softmax shift): 1.6 - 2.2e-3 relative L2 measured."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from lam_slide_amd import _lib\n"
+        "from oracle import latent_net\n"
+        "from test_hip_parity import build_net, _hip_taps\n"
+        "dev = torch.device('cuda:0')\n"
+        "out = {}\n"
+        "for name, kw, B, T, L in (('d512', dict(depth=1, in_dim=16, hidden_size=512, num_heads=16, mlp_ratio=2), 2, 30, 200),\n"
+        "                          ('d512_full', dict(depth=1, in_dim=16, hidden_size=512, num_heads=16, mlp_ratio=2), 40, 9, 256),\n"
+        "                          ('d256', dict(depth=1, in_dim=16, hidden_size=256, num_heads=16, mlp_ratio=2), 3, 20, 192),\n"
+        "                          ('d128', dict(depth=1, in_dim=16, hidden_size=128, num_heads=8, mlp_ratio=2), 5, 32, 130)):\n"
+        "    sh = latent_net.NetShape(**kw)\n"
+        "    net = build_net(sh, latent_net.random_params(sh, seed=21), dev); net.ensure_packed(dev)\n"
+        "    D = kw['hidden_size']; g = torch.Generator().manual_seed(3)\n"
+        "    h = torch.randn(B, T, L, D, generator=g).to(dev)\n"
+        "    mods = (torch.randn(B, 8 * D, generator=g) * 0.3).to(dev).contiguous()\n"
+        "    for bi in (0, 1):\n"
+        "        qkv, z = _hip_taps(net, _lib.load(), bi, h, mods, B, T, L, dev)\n"
+        "        out[f'{name}.{bi}.attn'] = z[:, :net.dims.hhd].clone(); out[f'{name}.{bi}.qkv'] = qkv.clone()\n"
+        "torch.save(out, sys.argv[1])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "1"):
+        path = f"/tmp/lsl_attn_{mode}_{os.getpid()}.pt"
+        env = dict({k: v for k, v in os.environ.items() if k != "LSL_ATTN_STREAM"}, LSL_ATTN_STREAM=mode)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=900)
+        res[mode] = torch.load(path)
+        os.remove(path)
+    for key in res["0"]:
+        a, b = res["0"][key], res["1"][key]
+        assert torch.isfinite(b).all(), key
+        if key.endswith(".qkv"):  # q / k / v are the same bits in either layout (lsl_debug_taps hands the planes out as rows)
+            assert torch.equal(a, b), key
+        else:
+            parity(f"attn_stream.{key}", rel_l2(b, a), 6e-3)
+
+
 def _hip_taps(net, lib, bi, h_in, mods, B, T, L, dev):
     """qkv / z of sub-block bi as the kernels leave them (lsl_debug_taps), as float tensors [n, 3, H, hdp] and [n, HHD + M]."""
     from lam_slide_amd import _lib
