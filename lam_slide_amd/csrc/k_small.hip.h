@@ -680,7 +680,10 @@ __global__ void __launch_bounds__(256) k_head_step(float *x, float *out, const f
 // workgroup a CU holds never waits on HBM with nothing else to do.
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 template <int NE>
-constexpr size_t head_mfma_lds_bytes() { return (size_t)HEAD_TOK * (NE * 64 + 4) * 4 + (size_t)4 * 32 * 33 * 4; }
+constexpr size_t head_mfma_lds_bytes(bool one_slab) {  // one_slab (C <= 32): the partial products overlay the activation rows, dead by then
+    constexpr size_t rows = (size_t)HEAD_TOK * (NE * 64 + 4) * 4, parts = (size_t)4 * 32 * 33 * 4;
+    return one_slab ? (rows > parts ? rows : parts) : rows + parts;
+}
 
 template <int NE, int VEC>
 __global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, const float *h, const float *shift, const float *scale,
@@ -691,12 +694,13 @@ __global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = NE * 64, AS = D + 4, RPW = HEAD_TOK / 4, KW = D / 4, JS = KW / 8;  // k range per wave, 8-deep steps per wave
     float *As = reinterpret_cast<float *>(smem);  // [HEAD_TOK][AS]  LayerNorm'ed + modulated rows
-    float *Ps = As + HEAD_TOK * AS;               // [4][32][33]     per-wave partial products (token, channel)
+    const bool w_resident = C <= 32;
+    float *Ps = w_resident ? As : As + HEAD_TOK * AS;  // [4][32][33] per-wave partial products (token, channel); one slab: over the dead rows
+                                                        // (66 instead of 83 KB at hidden 512: two workgroups per CU)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
     const int tk = tid >> 3, cg = tid & 7;
     const int n_tiles = (N + HEAD_TOK - 1) / HEAD_TOK;
-    const bool w_resident = C <= 32;
 
     float4 wf[JS];  // B operand: W^T[k][channel r] for this wave's k range, lane (r, hf) holds k = 8 j + 4 hf .. + 3
     auto load_w = [&](int c0) {
@@ -732,6 +736,13 @@ __global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, co
         if (tile + (int)gridDim.x < n_tiles) load_rows(tile + gridDim.x);  // in flight during the product below
         __syncthreads();
         const int n = n0 + tk;
+        // (one slab) the state values this thread will update are requested now, in front of the product, instead of behind it
+        float xs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w_resident && do_step && n < N) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * cg + j < C) xs[j] = x[(size_t)n * C + 4 * cg + j];
+        }
         for (int c0 = 0; c0 < C; c0 += 32) {
             if (!w_resident) load_w(c0);
             f32x16_t acc;
@@ -746,7 +757,7 @@ __global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, co
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wf[j].z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[j].w, acc, 0, 0, 0);
             }
-            if (c0) __syncthreads();  // the previous slab's partials have been consumed
+            if (c0 || w_resident) __syncthreads();  // the previous slab's partials have been consumed / every wave has read its activation rows
 #pragma unroll
             for (int e = 0; e < 16; ++e) Ps[(wave * 32 + acc_row(e, hf)) * 33 + r] = acc[e];
             __syncthreads();
@@ -759,7 +770,7 @@ __global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, co
                                         Ps[(3 * 32 + tk) * 33 + cl] + bo[c];
                         const size_t e = (size_t)n * C + c;
                         if (do_step) {
-                            float xn = ax * x[e] + am * m;
+                            float xn = ax * (w_resident ? xs[j] : x[e]) + am * m;
                             if (aw != 0.0f) xn += aw * (noise ? noise[e] : philox_normal(seed, step, elem_offset + e));
                             if (saved) xn += as * saved[e];  // (lsl_step_ex: a state kept by an earlier record, e.g. Heun's x_hat)
                             x[e] = xn;

@@ -245,9 +245,9 @@ void launch_head_mfma(float *x, float *out, const float *h, const float *shift, 
                       unsigned long long seed, unsigned step, unsigned long long eo, float *trace, float as, const float *saved, float *save_out,
                       hipStream_t st) {
     auto kern = k_head_step_mfma<NE, VEC>;
-    constexpr size_t lds = head_mfma_lds_bytes<NE>();
-    LSL_ALLOW_LDS(kern, lds);
-    // two workgroups per CU where the LDS image allows it (hidden <= 384): one workgroup's LayerNorm / weight-load latencies under the other's MFMAs
+    const size_t lds = head_mfma_lds_bytes<NE>(C <= 32);
+    LSL_ALLOW_LDS(kern, head_mfma_lds_bytes<NE>(false));
+    // two workgroups per CU where the LDS image allows it (any hidden size with <= 32 channels): one workgroup's LayerNorm / weight-load latencies under the other's MFMAs
     static const int per_cu = tune_int("LSL_HEAD_PER_CU", 2);
     const int wgs = device_cus() * (per_cu >= 2 && 2 * lds <= (size_t)160 * 1024 ? 2 : 1);
     hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, wgs)), dim3(256), lds, st, x, out, h, shift, scale, stride,
