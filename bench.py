@@ -17,7 +17,9 @@ relays rank 0's single JSON line.  Documented weak-scaling lines beside the head
     python bench.py --gpus N --workload peptide --batch 8       (BASELINE configs[3]: 1000-step SDE, 8 trajectories per GPU)
 
 Extra legs on rank 0 at N=1: ``roofline`` / ``roofline2`` (HIP-event timing of every launch of the dominant kernel, the linear1
-MFMA GEMM, and of linear2, in a separate un-overlapped pass after the timed region), ``gpu_small_batch`` (the same call at B=1 and B=8), ``stage1`` (device encode / decode
+MFMA GEMM, and of linear2, in a separate un-overlapped pass after the timed region), ``roofline_step`` (the whole step's HBM-side bytes, from
+the committed PMC profile, over this run's step time: the step as it is cut into kernels is HBM-bound), ``gpu_small_batch`` (the
+same call at B = 1, 8 and 64), ``stage1`` (device encode / decode
 of the batch, the steps either side of the loop) and ``cpu_baseline`` (the CPU oracle restatement timed on the
 host cores: the full solve of one trajectory, which is also this run's parity check, a 1-thread figure and an
 all-core figure with several trajectories in flight).
