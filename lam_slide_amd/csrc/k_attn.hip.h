@@ -28,7 +28,7 @@ struct AttnArgs {
     int hd;          // true head_dim (<= HDP).  hd < HDP (peptide: 24 of 32): the padding channels of v are zero, and k_attention_rows
                      // turns channel hd of the staged V into ones, so that row hd of O^T = V^T P^T IS the softmax denominator
     int bound;       // k_attention_rows: 1 = softmax shifted by the Cauchy-Schwarz bound |q| max|k| instead of the row maximum when that is safe
-    int planes, npad;    // k_attention_stream (HDP = 32, spatial): 1 = q / k / v are head-major planes qkv[section][head][npad tokens][32] (k_lin1.hip.h)
+    int planes, npad;    // k_attention_stream (spatial): 1 = q / k / v are head-major planes qkv[section][head][npad tokens][HDP] (k_lin1.hip.h)
     const float *kmax2;  // k_attention_stream: device scalar, an upper bound of |k_j|^2 for every key of this block (head_dim max_d ks_d^2: k_rope_scaled)
 };
 
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
     const bool has_tile = !LONG || wave < nkt;  // (uniform) LONG: wave w = query tile w
     const unsigned rs = 3u * a.HHD;
     const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))(smem);
-    const bool planes = LONG && HDP == 32 && a.planes;  // (uniform) plane layout: positions of a sequence are consecutive tokens (pos_stride 1)
+    const bool planes = LONG && a.planes;  // (uniform) plane layout: positions of a sequence are consecutive tokens (pos_stride 1)
 
     // per-lane parts of the addresses (constant over the units)
     unsigned voff_kv[IPW];

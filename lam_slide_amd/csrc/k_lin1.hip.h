@@ -43,7 +43,7 @@ struct Lin1Args {
     int nt;                         // streaming stores
     unsigned long long *dbg;        // timing-probe builds only (LIN1_PROBE & 128): per workgroup and wave, 4 cycle sums; else unused
     int wpt;                        // 0: the (tile, block) sequence is cut evenly over the grid; > 0: wpt workgroups per token tile, grid = wpt x tiles
-    int planes;                     // HDP = 32 only: 1 = q / k / v leave as head-major planes qkv[section][head][npad tokens][32] (a (sequence, head)'s rows are
+    int planes;                     // 1 = q / k / v leave as head-major planes qkv[section][head][npad tokens][HDP] (a (sequence, head)'s rows are
                                     // then contiguous: k_attention_stream's spatial units), 0 = token-major rows qkv[token][3 HHD]
     int npad;                       // tokens rounded up to 256 (the plane pitch)
 };
@@ -237,11 +237,13 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     // q / k / v as head-major planes (Lin1Args::planes, 32-wide heads): block b IS plane b (section x head); a token row of a plane is 64
     // bytes, and of the slab's row-wise lanes (row lane >> 3, chunk c = lane & 7) those with c >= 4 belong to the next plane: the same
     // flush with other constants - 8 rows x 64 B contiguous per plane and instruction
-    const bool planes = HDP == 32 && g.planes;  // (uniform)
-    const unsigned plane_bytes = 64u * (unsigned)g.npad;
-    const unsigned stride_q = planes ? 64u : 2u * 3 * g.HHD, stride_z = 2u * (g.HHD + g.M);
-    const unsigned blk_q = planes ? plane_bytes : 64u;  // bytes between the q / k / v destinations of consecutive blocks
-    const unsigned voff_q = planes ? ((lane >> 2) & 1) * (plane_bytes - 64u) + (lane >> 3) * 64 + 16 * (lane & 7) : (lane >> 3) * stride_q + 16 * (lane & 7);
+    // (16-wide heads: a block is two heads, the slab four; a plane row is 32 bytes = two chunks)
+    const bool planes = g.planes != 0;  // (uniform)
+    constexpr unsigned PROW = 2u * HDP, CPH = HDP / 8;  // bytes of a plane's token row, 16-byte chunks per head
+    const unsigned plane_bytes = PROW * (unsigned)g.npad;
+    const unsigned stride_q = planes ? PROW : 2u * 3 * g.HHD, stride_z = 2u * (g.HHD + g.M);
+    const unsigned blk_q = planes ? (32 / HDP) * plane_bytes : 64u;  // bytes between the q / k / v destinations of consecutive blocks
+    const unsigned voff_q = planes ? ((lane & 7) / CPH) * plane_bytes + (lane >> 3) * PROW + 16 * ((lane & 7) % CPH) : (lane >> 3) * stride_q + 16 * (lane & 7);
     const unsigned voff_z = (lane >> 3) * stride_z + 16 * (lane & 7);
     const int slab_z = 3 * (g.HHD >> 5);  // first block that goes to z (uniform; sections start on multiples of 64 features)
     const char *fl_base = nullptr;

@@ -55,13 +55,14 @@ __global__ void k_rope_scaled(RopeScaledJobs jobs, int hd, int hdp, float theta)
     jobs.out[job][i] = make_float4(c * s0, sn * s1, sn * s0, c * s1);
 }
 
-// q / k / v planes [3 H][npad][32] (Lin1Args::planes) -> token-major rows [n][3 H 32]: lsl_debug_taps hands the taps out in one layout
-__global__ void k_planes_to_rows(u16 *rows, const u16 *planes, int n, int npad, int heads3) {
+// q / k / v planes [3 H][npad][hdp] (Lin1Args::planes) -> token-major rows [n][3 H hdp]: lsl_debug_taps hands the taps out in one layout
+__global__ void k_planes_to_rows(u16 *rows, const u16 *planes, int n, int npad, int heads3, int hdp) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
-    if (i >= (long)n * heads3 * 4) return;
-    const int c = (int)(i & 3), p = (int)((i >> 2) % heads3);
-    const long tok = (i >> 2) / heads3;
-    *reinterpret_cast<u32x4 *>(rows + (tok * heads3 + p) * 32 + 8 * c) = *reinterpret_cast<const u32x4 *>(planes + ((long)p * npad + tok) * 32 + 8 * c);
+    const int cph = hdp / 8;
+    if (i >= (long)n * heads3 * cph) return;
+    const int c = (int)(i % cph), p = (int)((i / cph) % heads3);
+    const long tok = (i / cph) / heads3;
+    *reinterpret_cast<u32x4 *>(rows + (tok * heads3 + p) * hdp + 8 * c) = *reinterpret_cast<const u32x4 *>(planes + ((long)p * npad + tok) * hdp + 8 * c);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -601,10 +601,11 @@ int attention_stream_mode(int S, int H) {  // 0: k_attention_rows / tiny / onlin
     return 0;
 }
 // q / k / v as head-major planes (k_lin1.hip.h, Lin1Args::planes): spatial sub-blocks (positions = consecutive tokens) whose attention
-// runs the LONG stream kernel, 32-wide heads, token-stationary linear1.  LSL_QKV_PLANES=0 keeps token-major rows (A/B runs).
+// runs the LONG stream kernel, token-stationary linear1.  LSL_QKV_PLANES=0 keeps token-major rows (A/B runs).
 bool qkv_planes_ok(int hdp, int hidden, int heads, int S, bool temporal, bool lin1_ts) {
     static const int on = env_int("LSL_QKV_PLANES", 1);
-    return on && hdp == 32 && hidden == 512 && !temporal && lin1_ts && heads % 2 == 0 && attention_stream_mode(S, heads) == 2;
+    (void)hidden;
+    return on && !temporal && lin1_ts && heads % (64 / hdp) == 0 && attention_stream_mode(S, heads) == 2;
 }
 template <int HDP>
 bool launch_attention_stream(const AttnArgs &a, hipStream_t st) {
@@ -1445,9 +1446,9 @@ int lsl_debug_taps(lsl_model *m, int32_t bi, const float *h_in, const float *mod
     if (int rc = run_block(m, ws, bi, ws.h, mods, m->MODW, B, T, L, st, false, false, nullptr, true)) return rc;
     const bool temporal = bi & 1;
     if (qkv_planes_ok(m->d.head_dim_pad, m->d.hidden, m->d.heads, temporal ? T : L, temporal, linear1_ts_ok(m->d.head_dim_pad, m->d.hidden, m->F1, m->HHD, (int)n))) {
-        const long chunks = (long)n * 3 * m->d.heads * 4;  // the block left q / k / v as head-major planes: hand them out as token-major rows
+        const long chunks = (long)n * 3 * m->d.heads * (m->d.head_dim_pad / 8);  // the block left q / k / v as head-major planes: hand them out as token-major rows
         hipLaunchKernelGGL(k_planes_to_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (u16 *)qkv_out, ws.qkv, (int)n,
-                           (int)((n + 255) & ~(size_t)255), 3 * m->d.heads);
+                           (int)((n + 255) & ~(size_t)255), 3 * m->d.heads, m->d.head_dim_pad);
     } else
         hipMemcpyAsync(qkv_out, ws.qkv, n * 3 * m->HHD * 2, hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(z_out, ws.z, n * m->K2 * 2, hipMemcpyDeviceToDevice, st);
