@@ -623,6 +623,29 @@ def test_kernel_choice_knobs_do_not_change_bits(dev):
     assert torch.equal(res["default"], res["two_lanes"])
 
 
+@pytest.mark.parametrize("kw,B,T,L", [
+    (dict(depth=2, in_dim=32, hidden_size=512, num_heads=16, mlp_ratio=2), 20, 30, 256),   # headline model: k_linear2_ws<1536>, stream attention LONG (planes) + SHORT
+    (dict(depth=2, in_dim=32, hidden_size=256, num_heads=16, mlp_ratio=4), 300, 20, 8),    # NBA family: k_linear2_ws<1280> (5 chunks), SHORT with 16-wide heads
+    (dict(depth=2, in_dim=32, hidden_size=256, num_heads=16, mlp_ratio=2), 9, 30, 192),    # MD17 reference shape: k_linear2_ws<768>, LONG with 16-wide heads
+], ids=["md17", "nba", "md17_ref"])
+def test_general_path_rerun_bits(kw, B, T, L, dev):
+    """The round-4 kernels keep hand-counted vector-memory waits (LDS-DMA rings, hand-offs between waves through LDS): the same sampling
+    call repeated 25 times must give the same bits every time (a miscounted wait shows as a timing-dependent difference, as the resident
+    kernel's did in round 2)."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler
+    from oracle import latent_net
+    sh = latent_net.NetShape(**kw)
+    net = build_net(sh, latent_net.random_params(sh, seed=11), dev)
+    drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, 5), sampling_kwargs={"sampling_method": "euler", "num_steps": 4})
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(B, T, L, 32, generator=g).to(dev)
+    init = torch.randn(B, T, L, 32, generator=g).to(dev)
+    ref = drv.sample_latents(lat, init=init)
+    assert torch.isfinite(ref).all()
+    differing = sum(int(not torch.equal(drv.sample_latents(lat, init=init), ref)) for _ in range(25))
+    assert differing == 0, differing
+
+
 def test_attention_stream_kernel_against_rows_kernel(dev):
     """k_attention_stream (persistent, LDS-DMA double-buffered; the large axes of every config) against k_attention_rows (LSL_ATTN_STREAM=0)
     on the attention output of one spatial and one temporal sub-block: ragged last key tile (S = 200, 30, 9), both head widths, the
