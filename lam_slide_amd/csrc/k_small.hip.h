@@ -94,7 +94,8 @@ __global__ void k_time_features_steps(float *out, StepTimes st, int n_steps, int
 
 // ---------------------------------------------------------------------------------------------------
 // out[b][o] = post(sum_i W[o][i] * pre(in[b][i]) + bias[o] + add[b % add_mod][o]) (add_mod = 0: add[b]); one wave per output feature,
-// the weight row stays in registers while the wave walks the batch.  I <= 512.
+// the weight row stays in registers while the wave walks the batch (gridDim.y > 1: the rows in gridDim.y contiguous ranges; a row's sum
+// does not depend on how the rows are cut).  I <= 512.
 template <bool PRE_SILU, bool POST_SILU>
 __global__ void __launch_bounds__(256) k_dense_rows(float *out, const float *in, const float *W, const float *bias,
                                                     const float *add, int rows, int I, int O, int add_stride, int add_mod) {
@@ -108,7 +109,8 @@ __global__ void __launch_bounds__(256) k_dense_rows(float *out, const float *in,
         w[k] = i < I ? W[(size_t)o * I + i] : 0.0f;
     }
     const float bo = bias[o];
-    for (int b = 0; b < rows; ++b) {
+    const int rpb = (rows + (int)gridDim.y - 1) / (int)gridDim.y, b_hi = min(rows, ((int)blockIdx.y + 1) * rpb);
+    for (int b = (int)blockIdx.y * rpb; b < b_hi; ++b) {
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -240,19 +242,40 @@ __global__ void __launch_bounds__(256) k_dense_mfma(float *out, const float *in,
 // all output traffic is 16 bytes per lane) and walks every (256 / (D/4))-th token; the token's inputs are read
 // from LDS as wave-uniform 16-byte pieces.
 constexpr int EMB_TOK = 64;
+template <int CMAX, int ND>
+constexpr size_t embed_w_lds_bytes(int D) { return (size_t)(D / ND) * (ND * CMAX / 4 + 1) * 16; }
 template <int CMAX, int MODE, int ND>  // ND output columns per thread: 4 (C <= 32), 2 (C <= 96), 1
 __global__ void __launch_bounds__(256) k_embed(float *out, const float *in, const float *W, const float *bias,
                                                const float *bias2, const float *mask_emb, const int64_t *mask,
-                                               const float *base, int N, int C, int D) {
+                                               const float *base, int N, int C, int D, int w_lds, int tok) {
     __shared__ __attribute__((aligned(16))) float xs[EMB_TOK][CMAX];
-    const int n_tiles = (N + EMB_TOK - 1) / EMB_TOK;
+    extern __shared__ __attribute__((aligned(16))) float4 embed_w_lds[];  // w_lds: (D / ND) x (ND * CMAX / 4 + 1) 16-byte pieces
+    const int n_tiles = (N + tok - 1) / tok;  // tok <= EMB_TOK tokens per tile (small launches: smaller tiles, so that every CU gets work)
     const int DQ = D / ND, groups = DQ >= 256 ? 1 : 256 / DQ;
     // persistent workgroups: a thread's weight rows are fetched once and stay in registers while it walks the token tiles
     for (int dq = threadIdx.x % (DQ < 256 ? DQ : 256); dq < DQ; dq += 256) {
         const int tg = DQ >= 256 ? 0 : threadIdx.x / DQ, d = ND * dq;
         const bool active = tg < groups;  // (threads beyond groups * DQ only help with the staging)
         float w[ND][CMAX];
-        if ((C & 3) == 0) {  // 16-byte loads (every shipped model): a quarter of the load instructions of the per-element form, which made
+        if (w_lds) {
+            // C == CMAX: a thread's ND weight rows are ND * C * 4 contiguous bytes.  Fetched by the lanes directly, every load instruction
+            // touches 64 different 128-byte lines (16 bytes of each): ~10 us of prologue per workgroup, two thirds of the launch at
+            // 7 680 tokens.  Here the matrix is read in order (1 KiB per wave and instruction) into LDS, one (PIECES + 1) * 16-byte row per
+            // owner, and every thread picks its pieces from there: the same values in the same registers.
+            constexpr int PIECES = ND * CMAX / 4;
+            const int n4 = D * CMAX / 4;
+            const float4 *W4 = reinterpret_cast<const float4 *>(W);
+#pragma unroll 8
+            for (int i = threadIdx.x; i < n4; i += 256) embed_w_lds[(i / PIECES) * (PIECES + 1) + (i % PIECES)] = W4[i];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ND; ++j)
+#pragma unroll
+                for (int c = 0; c < CMAX; c += 4) {
+                    const float4 w4 = active ? embed_w_lds[dq * (PIECES + 1) + (j * CMAX + c) / 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    w[j][c] = w4.x; w[j][c + 1] = w4.y; w[j][c + 2] = w4.z; w[j][c + 3] = w4.w;
+                }
+        } else if ((C & 3) == 0) {  // 16-byte loads (every shipped model): a quarter of the load instructions of the per-element form, which made
                              // this prologue ~20 us of a 39 us launch at 23 000 tokens (md17 reference shape)
 #pragma unroll
             for (int j = 0; j < ND; ++j)
@@ -271,10 +294,10 @@ __global__ void __launch_bounds__(256) k_embed(float *out, const float *in, cons
 #pragma unroll
         for (int j = 0; j < ND; ++j) b0[j] = (MODE == 0 && active) ? bias[d + j] + bias2[d + j] : 0.0f;
         for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            const int n0 = tile * EMB_TOK;
-            const int ntok = min(EMB_TOK, N - n0);
+            const int n0 = tile * tok;
+            const int ntok = min(tok, N - n0);
             __syncthreads();  // the previous tile's products have finished reading xs
-            for (int i = threadIdx.x; i < EMB_TOK * CMAX; i += 256) {
+            for (int i = threadIdx.x; i < tok * CMAX; i += 256) {
                 const int tkn = i / CMAX, c = i % CMAX;
                 xs[tkn][c] = (tkn < ntok && c < C) ? in[(size_t)(n0 + tkn) * C + c] : 0.0f;
             }

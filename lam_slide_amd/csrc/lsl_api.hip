@@ -102,6 +102,10 @@ struct Workspace {
     size_t rope_qk_stride;  // float4 elements between consecutive (block, q|k) tables
     float *cond_emb, *h, *yemb, *tfeat, *hid, *vec, *mods;
     float *saved;  // [n][C] state kept by an LSL_STEP_SAVE record of lsl_sample_ex (Heun's x_hat)
+    // models without class conditioning: the modulation tables of a GROUP of sampler records are computed before the records run
+    // (one row per record: the time is shared by the batch), instead of four tiny dependent launches in front of every evaluation
+    float *tf_all, *hid_all, *vec_all, *mods_all;
+    int mods_group;  // records per group (0: class-conditioned model, tables per evaluation)
     u16 *a, *qkv, *z;
     float *kmax2;  // [2 * depth]: bound of |k|^2 per attention block (k_rope_scaled), for k_attention_stream's softmax shift
     u16 *w2p;  // linear2 weights of every sub-block in the fragment order of k_linear2_ws (k_lin2_pack, once per call), or NULL
@@ -136,6 +140,11 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.vec = (float *)take((size_t)bc * D * 4);
     ws.mods = (float *)take((size_t)bc * m->MODW * 4);
     ws.saved = (float *)take(n * d.in_dim * 4);
+    ws.mods_group = d.vec_in_dim > 0 ? 0 : (int)std::min<size_t>(1024, std::max<size_t>(1, ((size_t)16 << 20) / ((size_t)m->MODW * 4)));
+    ws.tf_all = (float *)take((size_t)ws.mods_group * 256 * 4);
+    ws.hid_all = (float *)take((size_t)ws.mods_group * D * 4);
+    ws.vec_all = (float *)take((size_t)ws.mods_group * D * 4);
+    ws.mods_all = (float *)take((size_t)ws.mods_group * m->MODW * 4);
     const size_t n_pad = align_up(n, 256);  // GEMM operand rows: whole 256-token tiles are read without clamping
     ws.a = (u16 *)take(n_pad * D * 2);
     ws.qkv = (u16 *)take(n_pad * 3 * m->HHD * 2);  // (padded like a / z: the token-stationary linear1 stores whole 256-token tiles)
@@ -301,11 +310,23 @@ int launch_embed(float *out, const float *in, const float *W, const float *b, co
 #undef LSL_EMB_CASE
         }
     }
-    const dim3 grid(std::min((n + EMB_TOK - 1) / EMB_TOK, 2 * device_cus())), blk(256);  // persistent: weights fetched once per workgroup
-    if (C <= 32) hipLaunchKernelGGL((k_embed<32, MODE, 4>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
-    else if (C <= 64) hipLaunchKernelGGL((k_embed<64, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
-    else if (C <= 96) hipLaunchKernelGGL((k_embed<96, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
-    else hipLaunchKernelGGL((k_embed<128, MODE, 1>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D);
+    // persistent workgroups (weights fetched once each) over tiles of 64 tokens
+    int tok = EMB_TOK;
+    // 32 inputs, hidden <= 512 (every shipped narrow-input model): the weight rows reach the registers through LDS (k_embed), which makes
+    // a workgroup's prologue cheap enough for 32- or 16-token tiles when the launch has fewer than two 64-token tiles per CU
+    static const int stage = tune_int("LSL_EMBED_LDS", 1);
+    const bool w_lds = stage && C == 32 && D % 4 == 0 && D <= 512;
+    if (w_lds)
+        while (tok > 16 && (n + tok - 1) / tok < 2 * device_cus()) tok /= 2;
+    const dim3 grid(std::min((n + tok - 1) / tok, 2 * device_cus())), blk(256);
+    if (C <= 32) {
+        const size_t lds = w_lds ? embed_w_lds_bytes<32, 4>(D) : 0;
+        auto kern = k_embed<32, MODE, 4>;
+        LSL_ALLOW_LDS(kern, (embed_w_lds_bytes<32, 4>(512)));
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, out, in, W, b, b2, me, mask, base, n, C, D, w_lds ? 1 : 0, tok);
+    } else if (C <= 64) hipLaunchKernelGGL((k_embed<64, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D, 0, tok);
+    else if (C <= 96) hipLaunchKernelGGL((k_embed<96, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D, 0, tok);
+    else hipLaunchKernelGGL((k_embed<128, MODE, 1>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D, 0, tok);
     return 0;
 }
 
@@ -721,6 +742,28 @@ int run_mods(lsl_model *m, const Workspace &ws, const float *t_dev, float t_scal
     return 0;
 }
 
+// The same tables for `count` sampler records at once (shared scalar time, no class vector: one row per record).  Every row goes
+// through the kernels run_mods uses for its single row (k_dense_rows: a row's sum does not depend on the other rows of the launch),
+// so a record's table has the same bits as the one run_mods computes in front of a single evaluation.
+int run_mods_steps(lsl_model *m, const Workspace &ws, const float *times, int count, hipStream_t st) {
+    const lsl_weights &w = m->w;
+    const int D = m->d.hidden;
+    m->prof.begin(6, st);
+    for (int c0 = 0; c0 < count; c0 += 48) {
+        StepTimes tt;
+        const int nc = std::min(48, count - c0);
+        for (int s = 0; s < nc; ++s) tt.t[s] = times[c0 + s];
+        hipLaunchKernelGGL(k_time_features_steps, dim3((nc * 128 + 255) / 256), dim3(256), 0, st, ws.tf_all + (size_t)c0 * 256, tt, nc, 1, w.time_freqs);
+    }
+    const unsigned gy = (unsigned)((count + 7) / 8);  // 8 rows per workgroup
+    hipLaunchKernelGGL((k_dense_rows<false, true>), dim3((D + 3) / 4, gy), dim3(256), 0, st, ws.hid_all, ws.tf_all, w.time_w1, w.time_b1, nullptr, count, 256, D, 0, 0);
+    hipLaunchKernelGGL((k_dense_rows<false, false>), dim3((D + 3) / 4, gy), dim3(256), 0, st, ws.vec_all, ws.hid_all, w.time_w2, w.time_b2, nullptr, count, D, D, D, 0);
+    hipLaunchKernelGGL((k_dense_rows<true, false>), dim3((m->MODW + 3) / 4, gy), dim3(256), 0, st, ws.mods_all, ws.vec_all, w.mod_w, w.mod_b, nullptr, count, D, m->MODW, 0, 0);
+    m->prof.end(6, st);
+    LSL_CHECK_LAUNCH("modulation (group of records)");
+    return 0;
+}
+
 // vec_in(y) (mmdit.py:118-126), constant over a sample
 int run_yemb(lsl_model *m, const Workspace &ws, const float *y, int rows, hipStream_t st) {
     const lsl_weights &w = m->w;
@@ -851,14 +894,18 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
 // do_step: fuse the affine update into the head; else write the network output to `out`.
 int run_eval(lsl_model *m, const Workspace &ws, float *x, float *out, const float *t_dev, float t_scalar, bool have_y, int bc,
              int T, int L, int do_step, float ax, float am, float aw, const float *noise, uint64_t seed, unsigned step,
-             uint64_t elem_off, float *trace, hipStream_t st, float as = 0.0f, const float *saved = nullptr, float *save_out = nullptr) {
+             uint64_t elem_off, float *trace, hipStream_t st, float as = 0.0f, const float *saved = nullptr, float *save_out = nullptr,
+             const float *mods_ready = nullptr) {
     const lsl_model_desc &d = m->d;
     const int D = d.hidden, n = bc * T * L;
     // modulation rows: one per trajectory, or a single shared row when t is a scalar and there is no y
     const bool shared = (t_dev == nullptr) && !have_y;
     const int rows = shared ? 1 : bc;
     const int mod_stride = shared ? 0 : m->MODW;
-    int rc = run_mods(m, ws, t_dev, t_scalar, have_y ? ws.yemb : nullptr, rows, ws.vec, ws.mods, st);
+    int rc = 0;
+    const float *mods = ws.mods;
+    if (mods_ready && shared) mods = mods_ready;  // this record's row of the group table (run_mods_steps)
+    else rc = run_mods(m, ws, t_dev, t_scalar, have_y ? ws.yemb : nullptr, rows, ws.vec, ws.mods, st);
     if (rc) return rc;
     m->prof.begin(5, st);
     launch_embed<1>(ws.h, x, m->w.x_in_w, nullptr, nullptr, nullptr, nullptr, ws.cond_emb, n, d.in_dim, D, st);
@@ -868,11 +915,11 @@ int run_eval(lsl_model *m, const Workspace &ws, float *x, float *out, const floa
     bool a_ready = false;  // the first sub-block of an evaluation runs the standalone LayerNorm; later ones get `a` from the previous linear2
     for (int bi = 0; bi < 2 * d.depth; ++bi) {
         bool wrote = false;
-        rc = run_block(m, ws, bi, ws.h, ws.mods, mod_stride, bc, T, L, st, a_ready, true, &wrote);
+        rc = run_block(m, ws, bi, ws.h, mods, mod_stride, bc, T, L, st, a_ready, true, &wrote);
         if (rc) return rc;
         a_ready = wrote;
     }
-    const float *fm = ws.mods + (size_t)d.depth * 6 * D;  // adaLN: shift, scale
+    const float *fm = mods + (size_t)d.depth * 6 * D;  // adaLN: shift, scale
     m->prof.begin(4, st);
     DISPATCH_D(D, launch_head_t, x, out, ws.h, fm, fm + D, mod_stride, m->w.out_w, m->w.out_b, n, d.in_dim, T * L, do_step, ax, am, aw,
                noise, (unsigned long long)seed, step, (unsigned long long)elem_off, trace, as, saved, save_out, st);
@@ -1350,6 +1397,21 @@ static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step_ex *ste
     }
     const size_t per = (size_t)io->T * io->L * m->d.in_dim;
     const size_t total = per * io->B;
+    // no class conditioning: modulation tables per group of network records, one row each (run_mods_steps); a lane recomputes a group only
+    // when its pass crosses into another one (calls of at most mods_group records: once per call).  LSL_MODS_GROUP=0: per evaluation.
+    // (>= 2: at most that many records per group - the GPU suite crosses group boundaries with it)
+    static const int group_on = env_int("LSL_MODS_GROUP", 1);
+    const int G = (group_on && !io->y && m->prof.kernel != 6) ? (group_on >= 2 ? std::min(group_on, wss[0].mods_group) : wss[0].mods_group) : 0;
+    std::vector<int> net_idx;
+    std::vector<float> net_t;
+    if (G) {
+        net_idx.resize((size_t)n_steps);
+        for (int s = 0; s < n_steps; ++s) {
+            net_idx[s] = (int)net_t.size();
+            if (!(steps[s].flags & LSL_STEP_NO_NETWORK)) net_t.push_back(steps[s].t);
+        }
+    }
+    int cur_group[2] = {-1, -1};
     // passes in groups of `lanes`; within a group the launches of the lanes are interleaved step by step so that both queues fill together
     for (int g0 = 0; g0 < io->B; g0 += chunk * lanes) {
         int b0s[2], bcs[2], nl = 0;
@@ -1382,8 +1444,17 @@ static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step_ex *ste
                     LSL_CHECK_LAUNCH("state update");
                     continue;
                 }
+                const float *mods_ready = nullptr;
+                if (G) {
+                    const int k = net_idx[s], g = k / G;
+                    if (cur_group[l] != g) {
+                        if (int rc = run_mods_steps(m, wss[l], net_t.data() + (size_t)g * G, std::min(G, (int)net_t.size() - g * G), lane_st[l])) return rc;
+                        cur_group[l] = g;
+                    }
+                    mods_ready = wss[l].mods_all + (size_t)(k - g * G) * m->MODW;
+                }
                 if (int rc = run_eval(m, wss[l], io->x + b0 * per, nullptr, nullptr, sp.t, io->y != nullptr, bcs[l], io->T, io->L, 1, sp.ax, sp.am, sp.aw,
-                                      nz, seed, (unsigned)sp.noise_index, elem_offset + b0 * per, tr, lane_st[l], sp.as, saved, save_out))
+                                      nz, seed, (unsigned)sp.noise_index, elem_offset + b0 * per, tr, lane_st[l], sp.as, saved, save_out, mods_ready))
                     return rc;
             }
         }
