@@ -742,19 +742,41 @@ __global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, co
     };
     if ((int)blockIdx.x < n_tiles) load_rows(blockIdx.x);
 
+    // a tile of 32 tokens nearly always lies inside ONE trajectory (and with a shared modulation row every tile does): the lane's shift /
+    // scale values then stay in registers across the tile's rows and across tiles, instead of 2 NE loads in front of every row's
+    // stores (128 dependent load instructions per wave and tile: the LayerNorm phase waited on them, profiles/r04_experiments.txt)
+    float sc1[NE], sh[NE];
+    int cur_traj = -1;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int n0 = tile * HEAD_TOK;
+        const int t_first = mod_stride ? n0 / tokens_per_traj : 0, t_last = mod_stride ? min(n0 + HEAD_TOK - 1, N - 1) / tokens_per_traj : 0;
+        const bool one_traj = t_first == t_last;  // (uniform)
+        if (one_traj && t_first != cur_traj) {
+            const size_t mo = (size_t)t_first * mod_stride;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int d = row_col<NE, VEC>(lane, k);
+                sc1[k] = 1.0f + scale[mo + d];
+                sh[k] = shift[mo + d];
+            }
+            cur_traj = t_first;
+        }
         __syncthreads();  // the previous tile has finished with As and Ps
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int n = min(n0 + wave + 4 * i, N - 1);
             float mean, rstd;
             row_stats<NE>(v[i], 1e-6f, mean, rstd);
-            const size_t mo = (size_t)(n / tokens_per_traj) * mod_stride;
+            if (one_traj) {
 #pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const int d = row_col<NE, VEC>(lane, k);
-                As[(wave + 4 * i) * AS + d] = (v[i][k] - mean) * rstd * (1.0f + scale[mo + d]) + shift[mo + d];
+                for (int k = 0; k < NE; ++k) As[(wave + 4 * i) * AS + row_col<NE, VEC>(lane, k)] = (v[i][k] - mean) * rstd * sc1[k] + sh[k];
+            } else {
+                const size_t mo = (size_t)(n / tokens_per_traj) * mod_stride;
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    const int d = row_col<NE, VEC>(lane, k);
+                    As[(wave + 4 * i) * AS + d] = (v[i][k] - mean) * rstd * (1.0f + scale[mo + d]) + shift[mo + d];
+                }
             }
         }
         if (tile + (int)gridDim.x < n_tiles) load_rows(tile + gridDim.x);  // in flight during the product below
