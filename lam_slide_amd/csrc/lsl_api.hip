@@ -758,8 +758,8 @@ int run_mods_steps(lsl_model *m, const Workspace &ws, const float *times, int co
     const unsigned gy = (unsigned)((count + 7) / 8);  // 8 rows per workgroup
     hipLaunchKernelGGL((k_dense_rows<false, true>), dim3((D + 3) / 4, gy), dim3(256), 0, st, ws.hid_all, ws.tf_all, w.time_w1, w.time_b1, nullptr, count, 256, D, 0, 0);
     hipLaunchKernelGGL((k_dense_rows<false, false>), dim3((D + 3) / 4, gy), dim3(256), 0, st, ws.vec_all, ws.hid_all, w.time_w2, w.time_b2, nullptr, count, D, D, D, 0);
-    // (the wide last layer: a workgroup's four weight rows are its HBM traffic, re-read once per row range - 64 rows per workgroup)
-    hipLaunchKernelGGL((k_dense_rows<true, false>), dim3((m->MODW + 3) / 4, (unsigned)((count + 63) / 64)), dim3(256), 0, st, ws.mods_all, ws.vec_all, w.mod_w, w.mod_b, nullptr, count, D, m->MODW, 0, 0);
+    // (the wide last layer: a workgroup's four weight rows are its HBM traffic, re-read once per row range - 16 rows per workgroup)
+    hipLaunchKernelGGL((k_dense_rows<true, false>), dim3((m->MODW + 3) / 4, (unsigned)((count + 15) / 16)), dim3(256), 0, st, ws.mods_all, ws.vec_all, w.mod_w, w.mod_b, nullptr, count, D, m->MODW, 0, 0);
     m->prof.end(6, st);
     LSL_CHECK_LAUNCH("modulation (group of records)");
     return 0;
