@@ -75,6 +75,9 @@ enum { LIN1_QK = 0, LIN1_V = 1, LIN1_MLP = 2 };
 #ifndef LIN1_PROBE
 #define LIN1_PROBE 0
 #endif
+#ifndef LIN1_ATTN_PROBE
+#define LIN1_ATTN_PROBE 0  // harness only: adds the per-head work of a fused spatial attention to the step (see fused())
+#endif
 #ifndef LIN1_PRIO
 #define LIN1_PRIO 0
 #endif
@@ -397,6 +400,9 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     if (LIN1_PROBE & 128) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_c0), "=s"(dbg_r0)::"memory");
     // fused step: MFMAs of block e + 1 beside the epilogue of block e (parity PAR = e & 1, section SEC).  FLUSH (PAR == 0 steps except the first
     // of a segment): the slab (e - 2, e - 1) is complete in the staging image and leaves during this step; PREV_FLUSHED: the previous step did
+#if LIN1_ATTN_PROBE
+    unsigned attn_probe_sink = 0;
+#endif
     auto fused = [&](auto sec_c, auto par_c, auto flush_c, auto prev_c, int e) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool FLUSH = decltype(flush_c)::value != 0;
@@ -431,6 +437,29 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         });
         advance(dma_blk);
         dma_slot = next_slot(dma_slot);
+#if LIN1_ATTN_PROBE
+        // (harness only, results unchanged but time added on purpose) the work a fused spatial attention would put into this wave once per
+        // head - 16 of the 80 blocks of a tile at cfg 2: 32 MFMAs with one LDS fragment read each (QK^T and PV of 32 queries x 256 keys),
+        // 128 v_exp_f32 and 64 packs per lane - as a separate phase behind the step, the way an in-order wave would run it
+        if (e % 5 == 4) {
+            f32x16 da;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) da[i] = 0.0f;
+            const char *sbp = smem + slot_c * BLK + aoff;
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) da = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(sbp + 32 * (ks % KS))), xreg[ks % KS], da);
+#pragma unroll
+            for (int rep = 0; rep < 8; ++rep)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) da[i] = __builtin_amdgcn_exp2f(da[i] * 0.001f);
+            unsigned acc_bits = 0;
+#pragma unroll
+            for (int rep = 0; rep < 8; ++rep)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) acc_bits ^= pack2(da[i] + (float)rep, da[i + 1]);
+            attn_probe_sink ^= acc_bits;
+        }
+#endif
         if (LIN1_PROBE & 128) {
             const unsigned long long t3 = stamp();
             dbg_sum[0] += t1 - t0; dbg_sum[1] += t2 - t1; dbg_sum[2] += t3 - t2; dbg_sum[3] += 1;
@@ -615,6 +644,9 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
             dbg_seg[3] += 1;
         }
     }
+#if LIN1_ATTN_PROBE
+    if (attn_probe_sink == 0x9E3779B9u && g.dbg) g.dbg[0] = attn_probe_sink;  // (keeps the probe's work alive)
+#endif
     wait_vmcnt<0>();  // the ring's run-ahead requests must not land in LDS after the workgroup has gone
     if ((LIN1_PROBE & 128) && lane == 0) {
 #pragma unroll
