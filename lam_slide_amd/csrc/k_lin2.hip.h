@@ -49,7 +49,7 @@ struct Lin2Args {
 };
 
 #ifndef LIN2_PROBE
-#define LIN2_PROBE 0  // tools/lin2_harness.hip only (results wrong): 1 no epilogue arithmetic + residual traffic, 2 no MFMAs, 4 no stores, 8 no token DMA, 32 no residual DMA, 128 cycle stamps
+#define LIN2_PROBE 0  // tools/lin2_harness.hip only (results wrong): 1 no epilogue arithmetic + residual traffic, 2 no MFMAs, 4 no stores, 8 no token DMA, 32 no residual DMA, 128 cycle stamps, 256 every MFMA twice (a second accumulator on the same operands: what a 64-feature wave would issue per fragment)
 #endif
 #ifndef LIN2_HI_FIRST
 #define LIN2_HI_FIRST 0  // 1: waves 0-3 (the older half, which wins the issue arbitration) finish the chains and run the epilogue
@@ -193,6 +193,9 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    f32x16 acc2;  // (LIN2_PROBE & 256 only)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
 
     // one chunk's MFMAs (chunk j of the block, in ring slot `slot`) with side jobs in their shadows: side(i) runs behind MFMA i
     auto chain = [&](auto jc, int slot, bool zero_start, auto side) __attribute__((always_inline)) {
@@ -213,6 +216,7 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
                     acc = mfma32(wreg[J * MPC + i], fr[i % PD], z);
                 } else
                     acc = mfma32(wreg[J * MPC + i], fr[i % PD], acc);
+                if (LIN2_PROBE & 256) acc2 = mfma32(wreg[J * MPC + i], fr[i % PD], acc2);  // (timing probe: a second feature tile's MFMAs on the same fragments)
                 if (i + PD < MPC) fr[i % PD] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * (i + PD)));
             }
             side(i);
@@ -319,6 +323,7 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
             }
         }
         wait_vmcnt<0>();  // the run-ahead requests must not land in LDS after the workgroup has gone
+        if ((LIN2_PROBE & 256) && acc2[0] + acc2[7] + acc2[15] == 12345.678f && g.dbg) g.dbg[1] = 1;
         dbg_out();
         return;
     }
@@ -454,5 +459,6 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
         for (int i = 0; i < 4; ++i) epi_store(b, i, ragged);
     }
     wait_vmcnt<0>();
+    if ((LIN2_PROBE & 256) && acc2[0] + acc2[7] + acc2[15] == 12345.678f && g.dbg) g.dbg[1] = 1;
     dbg_out();
 }
