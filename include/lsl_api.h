@@ -32,7 +32,7 @@ extern "C" {
 
 /* 2: lsl_sample_ex takes n_trace; linear1 biases are read in whole 256-feature tiles (b1 zero-padded to a multiple of 256 floats);
  *    lsl_sample_ex, lsl_debug_taps, lsl_build_info exist. */
-#define LSL_VERSION 2
+#define LSL_VERSION 3
 
 typedef struct lsl_model lsl_model;
 
@@ -174,6 +174,20 @@ int lsl_sample(lsl_model *m, const lsl_io *io, const lsl_step *steps, int32_t n_
  * 0xFFFFFFFF), element e of the call = global element elem_offset + e.  Stands in for `torch.randn_like(x_cond)`
  * (models/composites/lightning_base.py:231); shard-invariant by construction. */
 int lsl_randn(float *x, uint64_t n, uint64_t seed, uint64_t elem_offset, void *stream);
+
+/* Runge-Kutta arithmetic of the adaptive ODE sampler on the device (the reference's default ODE method is torchdiffeq's dopri5,
+ * modules/transport/transport.py:486-494 -> integrators.py:67-78; torchdiffeq's rk_common.py does these combinations with torch ops).  fp32;
+ * every term is a rounded product added to the rounded running sum in list order (no FMA contraction), reductions in a fixed order: results
+ * are deterministic and independent of the launch shape.  n_x, n_k <= 8; `out` may alias a term.
+ *   lsl_rk_lincomb:     out[i] = sum_j c[j] x[j][i]                       (stage states, solution, mid-point, dense-output coefficients)
+ *   lsl_rk_dense:       out[i] = e + x (d + x (c + x (b + x a)))           (dense output at the fraction x of an accepted step)
+ *   lsl_rk_error_ratio: *ratio = sqrt(mean_i (err[i] / (atol + rtol max(|y0[i]|, |y1[i]|)))^2), err = sum_j c[j] k[j]
+ *                       (the step controller's one scalar; `ratio` is a device pointer, `scratch` >= LSL_RK_SCRATCH_BYTES device bytes) */
+#define LSL_RK_SCRATCH_BYTES 8192
+int lsl_rk_lincomb(float *out, const float *const *x, const float *c, int32_t n_x, uint64_t n, void *stream);
+int lsl_rk_dense(float *out, const float *a, const float *b, const float *c, const float *d, const float *e, float x, uint64_t n, void *stream);
+int lsl_rk_error_ratio(float *ratio, const float *y0, const float *y1, const float *const *k, const float *c, int32_t n_k, float atol, float rtol,
+                       uint64_t n, void *scratch, void *stream);
 
 /* Test hooks: run a single kernel of the path on caller buffers (parity tests of intermediates). */
 int lsl_debug_block(lsl_model *m, int32_t block_index /* 0..2*depth-1 */, const float *h_in, float *h_out,

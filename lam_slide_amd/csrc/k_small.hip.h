@@ -552,6 +552,76 @@ __global__ void __launch_bounds__(256) k_ln_modulate_v4(u16 *a, const float *h, 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Runge-Kutta arithmetic of the adaptive ODE sampler (lam_slide_amd/transport.py: dopri5_solve; the reference reaches torchdiffeq's
+// rk_common.py through integrators.py:67-78): stage states, the solution, the dense-output coefficients and the error ratio of a step, fp32.
+// Every term is a rounded product added to a rounded running sum in the order of the list (no FMA contraction), so the result does not
+// depend on the launch shape; the host restatement used for CPU tensors follows the same order.
+struct RkTerms {
+    const float *x[8];
+    float c[8];
+    int n;
+};
+// a rounded product (hipcc builds device code with -ffp-contract=fast: a * b + c becomes an FMA in the backend whatever the spelling or the
+// pragma; the empty asm makes the product a value of its own)
+__device__ __forceinline__ float rk_mul(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__device__ __forceinline__ float rk_sum(const RkTerms &t, unsigned long long i) {
+    float acc = rk_mul(t.c[0], t.x[0][i]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+        if (j < t.n) acc = acc + rk_mul(t.c[j], t.x[j][i]);
+    return acc;
+}
+// out[i] = sum_j c[j] x[j][i]
+__global__ void __launch_bounds__(256) k_rk_lincomb(float *out, RkTerms t, unsigned long long n) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) out[i] = rk_sum(t, i);
+}
+// out[i] = e + x (d + x (c + x (b + x a))): the quartic dense output of an accepted step (rk_common.py: _interp_evaluate)
+__global__ void __launch_bounds__(256) k_rk_poly4(float *out, const float *a, const float *b, const float *c, const float *d, const float *e, float x,
+                                                  unsigned long long n) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        float v = b[i] + rk_mul(x, a[i]);
+        v = c[i] + rk_mul(x, v);
+        v = d[i] + rk_mul(x, v);
+        out[i] = e[i] + rk_mul(x, v);
+    }
+}
+// partial[b] = sum over block b's elements of (err[i] / (atol + rtol max(|y0[i]|, |y1[i]|)))^2, err = sum_j c[j] k[j]: fixed grid-stride
+// assignment, per-thread sums in element order, fixed tree over the block (deterministic)
+__global__ void __launch_bounds__(256) k_rk_error_partial(float *partial, const float *y0, const float *y1, RkTerms k, float atol, float rtol,
+                                                          unsigned long long n) {
+    __shared__ float red[256];
+    float s = 0.0f;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        const float q = rk_sum(k, i) / (atol + rtol * fmaxf(fabsf(y0[i]), fabsf(y1[i])));
+        s += q * q;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// *ratio = sqrt(sum_b partial[b] / n)
+__global__ void __launch_bounds__(256) k_rk_error_final(float *ratio, const float *partial, int n_partial, unsigned long long n) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < n_partial; b += 256) s += (double)partial[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *ratio = (float)sqrt(red[0] / (double)n);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller: standard normal for (seed, step, element).  Documented stream:
 // counter = (elem/4 lo, elem/4 hi, step, 0), key = (seed lo, seed hi); element e takes output e % 4
 // after Box-Muller on the pairs (r0,r1) -> (z0,z1), (r2,r3) -> (z2,z3).

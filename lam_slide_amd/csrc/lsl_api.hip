@@ -1483,6 +1483,59 @@ int lsl_randn(float *x, uint64_t n, uint64_t seed, uint64_t elem_offset, void *s
     return fail(-11, "unexpected C++ exception");
 }
 
+// ---- Runge-Kutta arithmetic of the adaptive sampler (k_small.hip.h: k_rk_*) ----
+static int rk_terms(RkTerms &t, const float *const *x, const float *c, int32_t n_x) {
+    if (!x || !c || n_x < 1 || n_x > 8) return fail(-3, "1 to 8 terms");
+    t.n = n_x;
+    for (int j = 0; j < 8; ++j) {
+        t.x[j] = j < n_x ? x[j] : nullptr;
+        t.c[j] = j < n_x ? c[j] : 0.0f;
+        if (j < n_x && !x[j]) return fail(-1, "null term pointer");
+    }
+    return 0;
+}
+static unsigned rk_grid(uint64_t n) { return (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)device_cus() * 8); }
+
+int lsl_rk_lincomb(float *out, const float *const *x, const float *c, int32_t n_x, uint64_t n, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
+    if (!out && n) return fail(-1, "null argument");
+    RkTerms t;
+    if (int rc = rk_terms(t, x, c, n_x)) return rc;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_rk_lincomb, dim3(rk_grid(n)), dim3(256), 0, (hipStream_t)stream, out, t, (unsigned long long)n);
+    LSL_CHECK_LAUNCH("lsl_rk_lincomb");
+    return 0;
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
+}
+
+int lsl_rk_dense(float *out, const float *a, const float *b, const float *c, const float *d, const float *e, float x, uint64_t n, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
+    if (n && (!out || !a || !b || !c || !d || !e)) return fail(-1, "null argument");
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_rk_poly4, dim3(rk_grid(n)), dim3(256), 0, (hipStream_t)stream, out, a, b, c, d, e, x, (unsigned long long)n);
+    LSL_CHECK_LAUNCH("lsl_rk_dense");
+    return 0;
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
+}
+
+int lsl_rk_error_ratio(float *ratio, const float *y0, const float *y1, const float *const *k, const float *c, int32_t n_k, float atol, float rtol,
+                       uint64_t n, void *scratch, void *stream) try {
+    DeviceGuard dev_guard_((hipStream_t)stream);
+    if (!ratio || !y0 || !y1 || !scratch) return fail(-1, "null argument");
+    if (!n) return fail(-3, "empty state");
+    RkTerms t;
+    if (int rc = rk_terms(t, k, c, n_k)) return rc;
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, LSL_RK_SCRATCH_BYTES / 4);  // (fixed for a given n: the sum's order is part of the contract)
+    hipLaunchKernelGGL(k_rk_error_partial, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)scratch, y0, y1, t, atol, rtol, (unsigned long long)n);
+    hipLaunchKernelGGL(k_rk_error_final, dim3(1), dim3(256), 0, (hipStream_t)stream, ratio, (const float *)scratch, (int)grid, (unsigned long long)n);
+    LSL_CHECK_LAUNCH("lsl_rk_error_ratio");
+    return 0;
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
+}
+
 int lsl_debug_block(lsl_model *m, int32_t bi, const float *h_in, float *h_out, const float *mods, int32_t B, int32_t T, int32_t L,
                     void *workspace, size_t workspace_bytes, void *stream) try {
     DeviceGuard dev_guard_((hipStream_t)stream);

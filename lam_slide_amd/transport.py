@@ -304,23 +304,83 @@ def _rms(v: Tensor) -> float:
     return float(v.double().pow(2).mean().sqrt())
 
 
+class _RkOps:
+    """The arithmetic of a Runge-Kutta step on whole states: linear combinations, the controller's error ratio, the quartic dense output.
+    fp32 CUDA tensors go through the library (``lsl_rk_lincomb`` / ``lsl_rk_error_ratio`` / ``lsl_rk_dense``: one launch per combination, terms
+    added in list order, deterministic reduction); anything else (CPU tensors of the host-logic tests, other dtypes) through torch operations
+    in the same order.  ``terms`` = [(coefficient, tensor), ...] with at most 8 entries."""
+
+    def __init__(self, like: Tensor):
+        self.hip = like.is_cuda and like.dtype == torch.float32
+        if self.hip:
+            self.lib = _lib.load()
+            self.dev = like.device
+            self.scratch = torch.empty(_lib.RK_SCRATCH_BYTES // 4, dtype=torch.float32, device=like.device)
+            self.ratio = torch.empty(1, dtype=torch.float32, device=like.device)
+
+    def _pack(self, terms):
+        xs = [x.contiguous() for _, x in terms]
+        ptrs = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        cs = (C.c_float * len(xs))(*[float(c) for c, _ in terms])
+        return xs, ptrs, cs
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def lincomb(self, terms) -> Tensor:
+        if not self.hip:
+            acc = terms[0][1] * _f32(terms[0][0])
+            for c, x in terms[1:]:
+                acc = acc + x * _f32(c)
+            return acc
+        xs, ptrs, cs = self._pack(terms)
+        out = torch.empty_like(xs[0])
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.lsl_rk_lincomb(out.data_ptr(), ptrs, cs, len(xs), out.numel(), self._stream()))
+        return out
+
+    def error_ratio(self, y0: Tensor, y1: Tensor, terms, atol: float, rtol: float) -> float:
+        """sqrt(mean((sum_j c_j k_j / (atol + rtol max(|y0|, |y1|)))^2)) as a host scalar (the one device sync of a step)."""
+        if not self.hip:
+            return _rms(self.lincomb(terms) / (atol + rtol * torch.maximum(y0.abs(), y1.abs())))
+        xs, ptrs, cs = self._pack(terms)
+        y0, y1 = y0.contiguous(), y1.contiguous()
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.lsl_rk_error_ratio(self.ratio.data_ptr(), y0.data_ptr(), y1.data_ptr(), ptrs, cs, len(xs), float(atol), float(rtol),
+                                                   y0.numel(), self.scratch.data_ptr(), self._stream()))
+        return float(self.ratio.item())
+
+    def poly4(self, a: Tensor, b: Tensor, c: Tensor, d: Tensor, e: Tensor, x: float) -> Tensor:
+        if not self.hip:
+            xf = _f32(x)
+            return e + xf * (d + xf * (c + xf * (b + xf * a)))
+        out = torch.empty_like(e)
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.lsl_rk_dense(out.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), e.data_ptr(), float(x), out.numel(),
+                                             self._stream()))
+        return out
+
+
 def dopri5_solve(f: Callable[[float, Tensor], Tensor], y0: Tensor, grid: Sequence[float], rtol: float, atol: float,
                  max_steps: int = 100000) -> Tuple[List[Tensor], Dict[str, int]]:
     """Solution of y' = f(t, y) at the (increasing) times `grid`, grid[0] being the initial time: [y(grid[0]), ..., y(grid[-1])] and
     counters.  Steps are chosen by the error controller alone and run past the output times; outputs are interpolated.  An output time
     that does not exceed the current time (repeated grid points, a single-point grid) returns the current state.  Time arithmetic runs in
     Python float64 (torchdiffeq keeps t in the dtype of the state's time tensor: accepted-step sequences agree in accuracy class, not in
-    the last bit); the error ratio is one host scalar per step (`_rms` -> float: a device sync per stage combination)."""
+    the last bit).  The state arithmetic of a step is ten launches of the library's Runge-Kutta kernels (`_RkOps`: six stage states, the
+    error ratio, and for an accepted step the mid-point and three dense-output coefficients); the error ratio is the one host scalar, and the
+    one device sync, of a step."""
+    y0 = y0.contiguous()
+    ops = _RkOps(y0)
     t0 = float(grid[0])
     f0 = f(t0, y0)
     nfe = 1
-    # initial step (Hairer, Norsett, Wanner I, II.4), order 4 estimate
-    scale = atol + y0.abs() * rtol
-    d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
+    # initial step (Hairer, Norsett, Wanner I, II.4), order 4 estimate; scale = atol + |y0| rtol
+    d0, d1 = ops.error_ratio(y0, y0, [(1.0, y0)], atol, rtol), ops.error_ratio(y0, y0, [(1.0, f0)], atol, rtol)
     h0 = 1e-6 if d0 < 1e-5 or d1 < 1e-5 else 0.01 * d0 / d1
-    f1 = f(t0 + h0, y0 + h0 * f0)
+    f1 = f(t0 + h0, ops.lincomb([(1.0, y0), (h0, f0)]))
     nfe += 1
-    d2 = _rms((f1 - f0) / scale) / h0
+    d2 = ops.error_ratio(y0, y0, [(1.0, f1), (-1.0, f0)], atol, rtol) / h0
     h1 = max(1e-6, h0 * 1e-3) if d1 <= 1e-15 and d2 <= 1e-15 else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
     dt = min(100 * h0, h1)
 
@@ -333,21 +393,20 @@ def dopri5_solve(f: Callable[[float, Tensor], Tensor], y0: Tensor, grid: Sequenc
             if accepted + rejected >= max_steps:
                 raise RuntimeError("dopri5: max_steps reached")
             k = [fy]
+            yi = y
             for a, beta in zip(_DP_ALPHA, _DP_BETA):
-                yi = y
-                for b, kj in zip(beta, k):
-                    if b != 0.0:
-                        yi = yi + (dt * b) * kj
+                yi = ops.lincomb([(1.0, y)] + [(dt * b, kj) for b, kj in zip(beta, k) if b != 0.0])
                 k.append(f(t + a * dt, yi))
             nfe += 6
             y1 = yi  # the last stage IS the 5th-order solution (beta[-1] = c_sol): first same as last
-            err = sum((dt * c) * kj for c, kj in zip(_DP_C_ERR, k) if c != 0.0)
-            ratio = _rms(err / (atol + rtol * torch.maximum(y.abs(), y1.abs())))
+            ratio = ops.error_ratio(y, y1, [(dt * c, kj) for c, kj in zip(_DP_C_ERR, k) if c != 0.0], atol, rtol)
             if ratio <= 1.0:
-                y_mid = y + sum((dt * c) * kj for c, kj in zip(_DP_C_MID, k) if c != 0.0)
+                y_mid = ops.lincomb([(1.0, y)] + [(dt * c, kj) for c, kj in zip(_DP_C_MID, k) if c != 0.0])
                 fa, fb = k[0], k[-1]
-                coeff = (y, dt * fa, dt * (fb - 4 * fa) - 11 * y - 5 * y1 + 16 * y_mid, dt * (5 * fa - 3 * fb) + 18 * y + 14 * y1 - 32 * y_mid,
-                         2 * dt * (fb - fa) - 8 * (y1 + y) + 16 * y_mid)
+                coeff = (y, ops.lincomb([(dt, fa)]),
+                         ops.lincomb([(dt, fb), (-4 * dt, fa), (-11.0, y), (-5.0, y1), (16.0, y_mid)]),
+                         ops.lincomb([(5 * dt, fa), (-3 * dt, fb), (18.0, y), (14.0, y1), (-32.0, y_mid)]),
+                         ops.lincomb([(2 * dt, fb), (-2 * dt, fa), (-8.0, y1), (-8.0, y), (16.0, y_mid)]))
                 t_lo, t, y, fy = t, t + dt, y1, k[-1]
                 accepted += 1
             else:
@@ -359,9 +418,8 @@ def dopri5_solve(f: Callable[[float, Tensor], Tensor], y0: Tensor, grid: Sequenc
         if coeff is None or t <= t_lo:  # an output time at (or before) the current time with no accepted step to interpolate: the state itself
             out.append(y)
             continue
-        x = (tn - t_lo) / (t - t_lo)
         e, d, c, b, a = coeff
-        out.append(e + x * (d + x * (c + x * (b + x * a))))
+        out.append(ops.poly4(a, b, c, d, e, (tn - t_lo) / (t - t_lo)))
     return out, {"nfe": nfe, "accepted": accepted, "rejected": rejected}
 
 

@@ -39,7 +39,7 @@ def build_net(sh, params, dev):
 def test_library_loaded_and_fails_loudly_on_cpu(dev):
     from lam_slide_amd import LatentSIV3, _lib
     lib = _lib.load()
-    assert lib.lsl_version() == _lib.ABI_VERSION == 2
+    assert lib.lsl_version() == _lib.ABI_VERSION == 3
     net = LatentSIV3(depth=1, in_dim=8, hidden_size=64, num_heads=4, reset_parameters=False)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 2, 3, 8), torch.zeros(1), torch.zeros(1, 2, 3, 8), torch.zeros(1, 2, 3, dtype=torch.long))
@@ -144,6 +144,35 @@ def test_ode_samplers_against_reference_outputs(golden, dev):
         s = _sampler(net, path, pred)
         res = s.get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": 6})(init, net, x_cond=xc, x_cond_mask=mask)
         parity(f"f4.ode6.{path}.{pred}", rel_l2(res[-1].cpu(), f[f"ode6.{path}.{pred}"]), 6e-4)
+
+
+def test_runge_kutta_arithmetic_kernels(dev):
+    """lsl_rk_lincomb / lsl_rk_dense / lsl_rk_error_ratio (the state arithmetic of the adaptive sampler) against the same operations with torch
+    ops: the combinations bit for bit (every term a rounded product added to the rounded running sum, in list order: what torch's
+    element-wise kernels do), the error ratio against a float64 evaluation; odd sizes, one to eight terms, an aliased output."""
+    from lam_slide_amd.transport import _RkOps, _f32
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 257, 30 * 256 * 32 + 5):
+        xs = [torch.randn(n, generator=g).to(dev) * (1 + j) for j in range(8)]
+        ops = _RkOps(xs[0])
+        assert ops.hip
+        for n_terms in (1, 2, 5, 8):
+            cs = [0.37 * (-1) ** j / (j + 1) for j in range(n_terms)]
+            terms = list(zip(cs, xs[:n_terms]))
+            want = xs[0] * _f32(cs[0])
+            for c, x in terms[1:]:
+                want = want + x * _f32(c)
+            assert torch.equal(ops.lincomb(terms), want), (n, n_terms)
+        a, b, c, d, e = xs[:5]
+        x = 0.3125 + 1e-3
+        xf = _f32(x)
+        assert torch.equal(ops.poly4(a, b, c, d, e, x), e + xf * (d + xf * (c + xf * (b + xf * a))))
+        terms = [(0.01, xs[2]), (-0.02, xs[3]), (0.005, xs[4])]
+        err = (0.01 * xs[2].double() - 0.02 * xs[3].double() + 0.005 * xs[4].double())
+        want = float((err / (1e-6 + 1e-3 * torch.maximum(xs[0].abs(), xs[1].abs()).double())).pow(2).mean().sqrt())
+        got = ops.error_ratio(xs[0], xs[1], terms, 1e-6, 1e-3)
+        assert got == ops.error_ratio(xs[0], xs[1], terms, 1e-6, 1e-3)  # deterministic
+        parity(f"rk.error_ratio.n{n}", abs(got - want) / want, 2e-5)
 
 
 def test_ode_dopri5_default_method_on_the_hip_network(golden, dev):
