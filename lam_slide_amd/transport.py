@@ -329,9 +329,10 @@ class _RkOps:
 
     def lincomb(self, terms) -> Tensor:
         if not self.hip:
-            acc = terms[0][1] * _f32(terms[0][0])
+            rnd = _f32 if terms[0][1].dtype == torch.float32 else float  # (the kernels take fp32 coefficients)
+            acc = terms[0][1] * rnd(terms[0][0])
             for c, x in terms[1:]:
-                acc = acc + x * _f32(c)
+                acc = acc + x * rnd(c)
             return acc
         xs, ptrs, cs = self._pack(terms)
         out = torch.empty_like(xs[0])
@@ -352,7 +353,7 @@ class _RkOps:
 
     def poly4(self, a: Tensor, b: Tensor, c: Tensor, d: Tensor, e: Tensor, x: float) -> Tensor:
         if not self.hip:
-            xf = _f32(x)
+            xf = _f32(x) if e.dtype == torch.float32 else float(x)
             return e + xf * (d + xf * (c + xf * (b + xf * a)))
         out = torch.empty_like(e)
         with torch.cuda.device(self.dev):
@@ -422,6 +423,40 @@ def dopri5_solve(f: Callable[[float, Tensor], Tensor], y0: Tensor, grid: Sequenc
         out.append(ops.poly4(a, b, c, d, e, (tn - t_lo) / (t - t_lo)))
     return out, {"nfe": nfe, "accepted": accepted, "rejected": rejected}
 
+
+
+# ---- torchdiffeq's other fixed-grid explicit methods (integrators.py:119 passes any `method` through) ------------------------------------
+# Restated from the published schemes, as torchdiffeq's fixed_grid.py / rk_common.py define them (parity unpinned like dopri5: the package is
+# absent): the grid is the output grid itself, one step per interval.  "rk4" is torchdiffeq's default fourth-order step, the 3/8 rule.
+FIXED_GRID_RK_METHODS = ("midpoint", "heun3", "rk4")
+
+
+def fixed_grid_rk_solve(f: Callable[[float, Tensor], Tensor], y0: Tensor, grid: Sequence[float], method: str) -> List[Tensor]:
+    """[y(grid[0]), ..., y(grid[-1])] of y' = f(t, y) with one explicit Runge-Kutta step of `method` per grid interval; stage states and
+    the update through `_RkOps` (library kernels for fp32 CUDA states)."""
+    if method not in FIXED_GRID_RK_METHODS:
+        raise NotImplementedError(f"fixed-grid method {method!r}")
+    y = y0.contiguous()
+    ops = _RkOps(y)
+    out = [y]
+    ts = [float(g) for g in grid]
+    for t0, t1 in zip(ts[:-1], ts[1:]):
+        dt = t1 - t0
+        k1 = f(t0, y)
+        if method == "midpoint":
+            k2 = f(t0 + dt / 2, ops.lincomb([(1.0, y), (dt / 2, k1)]))
+            y = ops.lincomb([(1.0, y), (dt, k2)])
+        elif method == "heun3":
+            k2 = f(t0 + dt / 3, ops.lincomb([(1.0, y), (dt / 3, k1)]))
+            k3 = f(t0 + 2 * dt / 3, ops.lincomb([(1.0, y), (2 * dt / 3, k2)]))
+            y = ops.lincomb([(1.0, y), (dt / 4, k1), (3 * dt / 4, k3)])
+        else:  # rk4: 3/8 rule
+            k2 = f(t0 + dt / 3, ops.lincomb([(1.0, y), (dt / 3, k1)]))
+            k3 = f(t0 + 2 * dt / 3, ops.lincomb([(1.0, y), (dt, k2), (-dt / 3, k1)]))
+            k4 = f(t1, ops.lincomb([(1.0, y), (dt, k1), (-dt, k2), (dt, k3)]))
+            y = ops.lincomb([(1.0, y), (dt / 8, k1), (3 * dt / 8, k2), (3 * dt / 8, k3), (dt / 8, k4)])
+        out.append(y)
+    return out
 
 
 class Sampler:
@@ -636,8 +671,8 @@ class Sampler:
 
     # ---- reference API --------------------------------------------------------------------------------------
     def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False):
-        if sampling_method == "dopri5":
-            return self._sample_ode_dopri5(num_steps=num_steps, atol=atol, rtol=rtol, reverse=reverse)
+        if sampling_method == "dopri5" or sampling_method in FIXED_GRID_RK_METHODS:
+            return self._sample_ode_dopri5(num_steps=num_steps, atol=atol, rtol=rtol, reverse=reverse, method=sampling_method)
         if sampling_method != "euler":
             # Other torchdiffeq solvers: not implemented here.  When this class stands in for the reference's Sampler (dropin.install) and
             # was given the reference's own Transport object, hand the call to the class it replaced instead of breaking a flow that worked
@@ -647,7 +682,7 @@ class Sampler:
             if orig is not None and hasattr(self._given_transport, "get_drift"):
                 return orig(self._given_transport).sample_ode(sampling_method=sampling_method, num_steps=num_steps, atol=atol, rtol=rtol,
                                                               reverse=reverse)
-            raise NotImplementedError(f"ODE solver {sampling_method!r}: torchdiffeq's fixed-grid 'euler' and adaptive 'dopri5' are "
+            raise NotImplementedError(f"ODE solver {sampling_method!r}: torchdiffeq's fixed-grid 'euler' / 'midpoint' / 'heun3' / 'rk4' and adaptive 'dopri5' are "
                                       "implemented (SURVEY.md 8c)")
         steps, grid = self.ode_steps(num_steps, reverse)
 
@@ -669,7 +704,7 @@ class Sampler:
 
         return _sample
 
-    def _sample_ode_dopri5(self, *, num_steps, atol, rtol, reverse):
+    def _sample_ode_dopri5(self, *, num_steps, atol, rtol, reverse, method="dopri5"):
         """The reference's default ODE sampler (transport.py:486-494, integrators.py:67-78 with method "dopri5"): adaptive steps, the solution
         reported at linspace(t0, t1, num_steps).  Every network evaluation runs on the HIP path (LatentSIV3.forward); the stage
         combinations and the error norm are a handful of element-wise device operations per step."""
@@ -679,13 +714,16 @@ class Sampler:
         grid = [float(g) for g in torch.linspace(t0, t1, num_steps)]
 
         def _sample(init, model, **model_kwargs):
-            self.last_path = "dopri5"
+            self.last_path = method
 
             def f(t, x):
                 tv = torch.ones(x.size(0), device=x.device) * (_f32(1 - t) if reverse else t)
                 return self._vel(x, tv, model, **model_kwargs)[0]
 
-            ys, self.last_ode_stats = dopri5_solve(f, init, grid, rtol, atol)
+            if method == "dopri5":
+                ys, self.last_ode_stats = dopri5_solve(f, init, grid, rtol, atol)
+            else:  # (torchdiffeq's fixed-grid midpoint / heun3 / rk4: one step per output interval)
+                ys = fixed_grid_rk_solve(f, init, grid, method)
             return torch.stack(ys)
 
         return _sample

@@ -104,13 +104,15 @@ def test_install_rebinds_the_module_level_sampler_without_source_edits():
         fn = lb.Sampler(lam_slide_amd.CreateTransport("GVP", "data")()).get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": 3})
         out = fn(torch.zeros(1, 2, 2, 2), lambda x, t, **kw: x)
         assert out.shape == (3, 1, 2, 2, 2)
-        # what this package does not implement (torchdiffeq solvers other than euler / dopri5) goes back to the class that was replaced when
-        # the call carries the reference's own Transport object; with this package's Transport there is nobody to hand it to
+        # what this package does not implement (torchdiffeq solvers other than euler / midpoint / heun3 / rk4 / dopri5) goes back to the class
+        # that was replaced when the call carries the reference's own Transport object; with this package's Transport there is nobody to hand it to
         ref_tr = RefTransport()
-        got = lb.Sampler(ref_tr).get_sample_fn("ODE", {"sampling_method": "rk4", "num_steps": 7})
-        assert got == ("reference rk4", ref_tr, 7)
+        got = lb.Sampler(ref_tr).get_sample_fn("ODE", {"sampling_method": "dopri8", "num_steps": 7})
+        assert got == ("reference dopri8", ref_tr, 7)
         with pytest.raises(NotImplementedError):
-            lb.Sampler(lam_slide_amd.CreateTransport("GVP", "data")()).get_sample_fn("ODE", {"sampling_method": "rk4"})
+            lb.Sampler(lam_slide_amd.CreateTransport("GVP", "data")()).get_sample_fn("ODE", {"sampling_method": "dopri8"})
+        # torchdiffeq's other fixed-grid methods are native too
+        assert callable(lb.Sampler(ref_tr).get_sample_fn("ODE", {"sampling_method": "rk4", "num_steps": 7}))
         # the reference's ODE default (dopri5) is native: a callable sample function, also for the reference's own Transport
         assert callable(lb.Sampler(ref_tr).get_sample_fn("ODE", {"num_steps": 7}))
         dropin.uninstall()

@@ -201,6 +201,27 @@ def test_ode_dopri5_default_method_on_the_hip_network(golden, dev):
             assert abs(s.last_ode_stats["accepted"] - so.last_ode_stats["accepted"]) <= 3 + so.last_ode_stats["accepted"] // 4
 
 
+def test_ode_fixed_grid_runge_kutta_methods_on_the_hip_network(golden, dev):
+    """torchdiffeq's other fixed-grid methods (midpoint, heun3, rk4; integrators.py:119 passes any `method` through): HIP network + library
+    Runge-Kutta kernels against the same scheme driven by the pinned oracle network on the CPU (no step control: the two runs differ by the
+    kernels' rounding only).  The 3/8 rule's last stage sits at y + dt (k1 - k2 + k3) - differences of network outputs that each carry the
+    bf16 path's ~1e-3 error - so its bar is wider (2.6e-3 measured at five coarse steps)."""
+    from oracle import latent_net
+    from lam_slide_amd.transport import FIXED_GRID_RK_METHODS
+    f = golden("f4_sampler.npz")
+    sh = shape_from(f.group("shape"))
+    p = f.group("p")
+    net = build_net(sh, p, dev)
+    init, xc, mask = f["init"], f["x_cond"], f["mask"]
+    oracle_model = lambda x, t, **kw: latent_net.forward(p, sh, x, t, kw["x_cond"], kw["x_cond_mask"], None)
+    for method in FIXED_GRID_RK_METHODS:
+        s = _sampler(net, "GVP", "data")
+        res = s.get_sample_fn("ODE", {"sampling_method": method, "num_steps": 6})(init.to(dev), net, x_cond=xc.to(dev), x_cond_mask=mask.to(dev))
+        assert s.last_path == method and len(res) == 6 and net.last_path == "hip" and torch.equal(res[0].cpu(), init)
+        want = _sampler(net, "GVP", "data").get_sample_fn("ODE", {"sampling_method": method, "num_steps": 6})(init, oracle_model, x_cond=xc, x_cond_mask=mask)
+        parity(f"f4.{method}.GVP.data", rel_l2(res[-1].cpu(), want[-1]), 5e-3 if method == "rk4" else 1e-3)
+
+
 def test_sde_samplers_with_stored_noise(golden, dev):
     f = golden("f4_sampler.npz")
     sh = shape_from(f.group("shape"))

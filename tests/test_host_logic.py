@@ -445,6 +445,29 @@ def test_dopri5_solver_against_exact_solution_and_scipy():
     assert torch.equal(ys_r[0], y0) and torch.equal(ys_r[1], y0) and torch.allclose(ys_r[2], ys_r[3], rtol=0, atol=0)
 
 
+def test_fixed_grid_runge_kutta_methods_have_their_orders():
+    """torchdiffeq's other fixed-grid methods (midpoint, heun3, rk4 = 3/8 rule; transport.fixed_grid_rk_solve, parity with torchdiffeq unpinned:
+    absent): on y' = -2 t y + cos t the error at t = 1.5 falls by 2^order when the step is halved, and every method returns one state per
+    grid point starting with the initial one."""
+    import numpy as np
+    from scipy.integrate import solve_ivp
+    from lam_slide_amd.transport import FIXED_GRID_RK_METHODS, fixed_grid_rk_solve
+    y0 = torch.tensor([0.7, -1.3], dtype=torch.float64)
+    import math
+    f = lambda t, y: -2.0 * t * y + math.cos(t)
+    exact = solve_ivp(lambda t, y: -2.0 * t * y + np.cos(t), (0.0, 1.5), y0.numpy(), method="DOP853", rtol=1e-13, atol=1e-14).y[:, -1]
+    for method, order in zip(FIXED_GRID_RK_METHODS, (2, 3, 4)):
+        errs = []
+        for n in (16, 32, 64):
+            ys = fixed_grid_rk_solve(f, y0, list(np.linspace(0.0, 1.5, n + 1)), method)
+            assert len(ys) == n + 1 and torch.equal(ys[0], y0)
+            errs.append(float(np.abs(ys[-1].numpy() - exact).max()))
+        for a, b in zip(errs[:-1], errs[1:]):
+            assert 0.8 * 2 ** order < a / b < 1.25 * 2 ** order, (method, errs)
+    with pytest.raises(NotImplementedError):
+        fixed_grid_rk_solve(f, y0, [0.0, 1.0], "bosh3")
+
+
 @pytest.mark.parametrize("path,pred,reverse", [("GVP", "data", False), ("Linear", "velocity", False), ("VP", "noise", False)])
 def test_sample_ode_dopri5_default_method_runs_and_converges(path, pred, reverse):
     """get_sample_fn("ODE", {}) - the reference's defaults (dopri5, 50 outputs, atol 1e-6, rtol 1e-3) - on a callable model: same states as
