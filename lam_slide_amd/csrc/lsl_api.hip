@@ -1402,7 +1402,7 @@ static int sample_enqueue(lsl_model *m, const lsl_io *io, const lsl_step_ex *ste
     // when its pass crosses into another one (calls of at most mods_group records: once per call).  LSL_MODS_GROUP=0: per evaluation.
     // (>= 2: at most that many records per group - the GPU suite crosses group boundaries with it)
     static const int group_on = env_int("LSL_MODS_GROUP", 1);
-    const int G = (group_on && !io->y && m->prof.kernel != 6) ? (group_on >= 2 ? std::min(group_on, wss[0].mods_group) : wss[0].mods_group) : 0;
+    const int G = (group_on && !io->y) ? (group_on >= 2 ? std::min(group_on, wss[0].mods_group) : wss[0].mods_group) : 0;
     std::vector<int> net_idx;
     std::vector<float> net_t;
     if (G) {
