@@ -1,0 +1,83 @@
+"""Random supported shapes through the HIP path against the CPU oracle (not part of the test suite: a sweep for edge cases of the kernel
+choices - ragged token counts, axes of every length class, every hidden size, shared / per-trajectory modulation):
+    python tools/fuzz_shapes.py [n_cases] [seed]
+For each case: one forward evaluation and a 3-update fused ODE sampling call, relative L2 against the oracle; prints the worst cases."""
+import random
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from lam_slide_amd import CreateTransport, SecondStageSampler  # noqa: E402
+from oracle import latent_net, transport as otr  # noqa: E402
+from test_hip_parity import build_net  # noqa: E402
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    dev = torch.device("cuda:0")
+    worst = []
+    t_start = time.time()
+    for case in range(n_cases):
+        D = rng.choice([128, 256, 384, 512, 64, 192])
+        heads = rng.choice([h for h in (4, 8, 16) if D % h == 0 and D // h <= 32 and (D // h) % 2 == 0 and (h * (16 if D // h <= 16 else 32)) % 32 == 0])
+        mlp = rng.choice([2, 4])
+        C = rng.choice([8, 16, 32, 32, 32, 48])
+        vec = rng.choice([0, 0, 0, 6])
+        depth = rng.choice([1, 2])
+        T = rng.choice([1, 2, 5, 9, 20, 30, 33, 64])
+        L = rng.choice([1, 2, 8, 21, 40, 130, 192, 256])
+        B = rng.choice([1, 2, 3, 5, 7])
+        while B * T * L > 40000:
+            B = max(1, B - 1)
+            if B == 1 and T * L > 40000:
+                L = max(1, L // 2)
+        kw = dict(depth=depth, in_dim=C, hidden_size=D, num_heads=heads, mlp_ratio=mlp)
+        if vec:
+            kw["vec_in_dim"] = vec
+        try:
+            sh = latent_net.NetShape(**kw)
+            p = latent_net.random_params(sh, seed=case + 100)
+            net = build_net(sh, p, dev)
+        except Exception as e:  # unsupported combination: fine, as long as it says so
+            print(f"case {case}: {kw} rejected: {type(e).__name__}: {str(e)[:80]}")
+            continue
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn(B, T, L, C, generator=g)
+        xc = torch.randn(B, T, L, C, generator=g)
+        mask = (torch.rand(B, T, L, generator=g) < 0.3).long()
+        t = torch.rand(B, generator=g)
+        y = torch.randn(B, vec, generator=g) if vec else None
+        want = latent_net.forward(p, sh, x, t, xc, mask, y)
+        got = net(x.to(dev), t.to(dev), xc.to(dev), mask.to(dev), y.to(dev) if y is not None else None).cpu()
+        e_fwd = rel_l2(got, want)
+        # fused sampler: 3 Euler updates, conditioning on frames 0..min(T, 2)
+        e_smp = float("nan")
+        if vec == 0:
+            drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, min(T, 2)),
+                                     sampling_kwargs={"sampling_method": "euler", "num_steps": 4})
+            lat = torch.randn(B, T, L, C, generator=g)
+            init = torch.randn(B, T, L, C, generator=g)
+            res = drv.sample_latents(lat.to(dev), init=init.to(dev)).cpu()
+            from lam_slide_amd import setup_conditioning
+            x_cond, m2 = setup_conditioning(lat, (0, min(T, 2)), True)
+            tro = otr.Transport("GVP", "data")
+            model = lambda xx, tt, **k: latent_net.forward(p, sh, xx, tt, k["x_cond"], k["x_cond_mask"], None)
+            ref = otr.sample_ode(tro, init, model, num_steps=4, sampling_method="euler", x_cond=x_cond, x_cond_mask=m2)[-1]
+            e_smp = rel_l2(res, ref)
+        bad = not (e_fwd < 2e-3) or (e_smp == e_smp and not (e_smp < 2e-3))
+        print(f"case {case}: D={D} H={heads} mlp={mlp} C={C} vec={vec} depth={depth} B={B} T={T} L={L}: forward {e_fwd:.2e} sampler {e_smp:.2e}{'   <-- CHECK' if bad else ''}", flush=True)
+        worst.append((max(e_fwd, e_smp if e_smp == e_smp else 0.0), case))
+    worst.sort(reverse=True)
+    print("worst:", worst[:5], f"({time.time() - t_start:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()
