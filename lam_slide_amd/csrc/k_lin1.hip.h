@@ -9,7 +9,7 @@
 //   * a workgroup = 8 waves = 256 tokens; wave w KEEPS its 32 tokens x K activations in registers as the MFMA B fragments of all K / 16
 //     k-steps (K / 4 VGPRs: 128 at K = 512), loaded once per token tile;
 //   * the weights stream through LDS in blocks of 32 features x K (one head of 32, or two of 16): a ring of 3 blocks filled by LDS-DMA,
-//     two blocks ahead, ONE workgroup barrier per block; every wave reads the whole block (A fragments, ds_read_b128, XOR-swizzled on the
+//     two blocks ahead, ONE workgroup barrier per block (K <= 256: 4 blocks, one barrier per two - LIN1_B2 below); every wave reads the whole block (A fragments, ds_read_b128, XOR-swizzled on the
 //     DMA source side).  Operand feed per FLOP is HALF that of a 256 x 256 tile (the activations never re-stream) and every byte of it
 //     is an L2 hit (the weight matrix is 2.6 MB);
 //   * per block a wave issues K / 16 MFMAs into ONE 32 x 32 accumulator tile (a single dependent chain runs at the full MFMA rate) while
@@ -48,6 +48,15 @@ struct Lin1Args {
     int npad;                       // tokens rounded up to 256 (the plane pitch)
 };
 
+// K <= 256 (a block is 16 or 8 MFMAs per wave against the same per-step head): 4 ring slots and ONE wait + barrier per PAIR of blocks - both
+// blocks of the next pair are requested in the pair's first step (8 instructions behind its 8 slices), confirmed at the head of the next pair.
+// Bit-identical (tools/gpu_lin1b2.sh: 22 harness runs); 163 840 x 256: 0.206 -> 0.198 ms, 10 240 x 256: 19.3 -> 18.8 us.  K = 384 / 512 have no LDS
+// for a fourth slot, and the barrier is not what costs there: the same pairing with the two halves of the workgroup swapping priority every
+// step (2) gains nothing - the halves' skew is the SIMD's issue arbitration, not the barrier count (profiles/r04_experiments.txt).
+#ifndef LIN1_B2
+#define LIN1_B2 1
+#endif
+
 template <int HDP, int K>
 struct Lin1Cfg {
     static_assert(K % 128 == 0 && K <= 512, "hidden sizes 128 / 256 / 384 / 512");
@@ -59,7 +68,7 @@ struct Lin1Cfg {
     // k-step ks is one per-lane base + the immediate 32 ks.
     static constexpr int PITCH = ROWB + 16;
     static constexpr int BLK = 32 * PITCH;              // one weight block
-    static constexpr int NS = 3;                        // ring slots
+    static constexpr int NS = (LIN1_B2 && K <= 256) ? 4 : 3;  // ring slots
     static constexpr int RING = NS * BLK;
     static constexpr int STAGE = 8 * 4096;              // wave-private output staging
     static constexpr int LPR = ROWB / 16;               // active lanes of a DMA instruction: 64 / 48 / 32 / 16
@@ -220,10 +229,16 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     // flight: no head waits for the acknowledgement of a store issued less than a step ago.  Extra younger operations only make a
     // counted wait conservative, never wrong.  Then the workgroup barrier: every wave's pieces have landed and every wave has left the
     // previous block, whose slot is free for the block two ahead.
+    constexpr bool B2 = LIN1_B2 != 0 && K <= 256;
     auto step_head = [&](auto flushed_c) __attribute__((always_inline)) {
         if (LIN1_PROBE & 16) return;
-        if (decltype(flushed_c)::value) wait_vmcnt<2 * PPW>();
-        else wait_vmcnt<PPW>();
+        if (B2) {  // (head of a pair of blocks: both were requested two steps ago, behind them only the previous step's slab stores)
+            if (decltype(flushed_c)::value) wait_vmcnt<PPW>();
+            else wait_vmcnt<0>();
+        } else {
+            if (decltype(flushed_c)::value) wait_vmcnt<2 * PPW>();
+            else wait_vmcnt<PPW>();
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
@@ -415,12 +430,20 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
             return t;
         };
         if (LIN1_PROBE & 128) t0 = stamp();
-        step_head(prev_c);
+        if (!B2 || PAR == 1) step_head(prev_c);  // (B2: the pair (e + 1, e + 2) starts with the odd e)
+        if (B2 && LIN1_B2 >= 2) {  // (wave-uniform branch: the builtin takes a constant)
+            if ((((wave >> 2) ^ PAR) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         if (LIN1_PROBE & 128) t1 = stamp();
         u32x4 pk[2];
         if (FLUSH) flush_setup(e - 2);
         const char *src = req_src(dma_blk);
         const unsigned dst = req_dst(dma_slot);
+        int blk2 = dma_blk;
+        advance(blk2);
+        const char *src2 = req_src(blk2);
+        const unsigned dst2 = req_dst(next_slot(dma_slot));
         init_acc(PAR ? acc0 : acc1, e + 1);
         if (LIN1_PROBE & 128) t2 = stamp();
         step(sec_c, par_c, I1, I1, [&](auto sl) __attribute__((always_inline)) {
@@ -433,10 +456,21 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
                 }
                 if (SL == 1) flush_store(1, pk);
             }
-            if (SL >= 2 && SL < 2 + PPW) issue_piece(src, dst, std::integral_constant<int, (SL >= 2 && SL < 2 + PPW) ? SL - 2 : 0>());
+            if (!B2) {
+                if (SL >= 2 && SL < 2 + PPW) issue_piece(src, dst, std::integral_constant<int, (SL >= 2 && SL < 2 + PPW) ? SL - 2 : 0>());
+            } else if (PAR == 1) {  // both blocks of the next pair: 8 pieces behind the 8 slices (PAR == 1 steps never flush)
+                if (SL >= 0 && SL < PPW) issue_piece(src, dst, std::integral_constant<int, (SL >= 0 && SL < PPW) ? SL : 0>());
+                if (SL >= PPW && SL < 2 * PPW) issue_piece(src2, dst2, std::integral_constant<int, (SL >= PPW && SL < 2 * PPW) ? SL - PPW : 0>());
+            }
         });
-        advance(dma_blk);
-        dma_slot = next_slot(dma_slot);
+        if (!B2) {
+            advance(dma_blk);
+            dma_slot = next_slot(dma_slot);
+        } else if (PAR == 1) {
+            advance(dma_blk);
+            advance(dma_blk);
+            dma_slot = next_slot(next_slot(dma_slot));
+        }
 #if LIN1_ATTN_PROBE
         // (harness only, results unchanged but time added on purpose) the work a fused spatial attention would put into this wave once per
         // head - 16 of the 80 blocks of a tile at cfg 2: 32 MFMAs with one LDS fragment read each (QK^T and PV of 32 queries x 256 keys),
@@ -560,6 +594,15 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         issue(dma_blk, dma_slot);
         advance(dma_blk);
         dma_slot = next_slot(dma_slot);
+        if (B2) {  // (the pair's second block too)
+            issue(dma_blk, dma_slot);
+            advance(dma_blk);
+            dma_slot = next_slot(dma_slot);
+            if (LIN1_B2 >= 2) {
+                if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
         init_acc(acc0, b0);
         if (LIN1_PROBE & 128) tp0 = kstamp();
         step(SV, I1, I1, I0, no_side);

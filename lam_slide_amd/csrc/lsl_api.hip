@@ -454,7 +454,7 @@ void launch_linear1_ts_t(const Lin1Args &a, hipStream_t st) {
 bool linear1_ts_ok(int hdp, int D, int F1, int HHD, int N) {
     static const int on = tune_int("LSL_LIN1_TS", 1);
     if (!on || (hdp != 16 && hdp != 32) || (D != 128 && D != 256 && D != 384 && D != 512) || F1 % 64 != 0 || HHD % 64 != 0 || N < 1) return false;
-    return (size_t)3 * 32 * (2 * D + 16) + 8 * 4096 + (size_t)F1 * 4 <= (size_t)163840;  // weight ring + staging + bias vector (Lin1Cfg::lds_bytes)
+    return (size_t)(D <= 256 ? 4 : 3) * 32 * (2 * D + 16) + 8 * 4096 + (size_t)F1 * 4 <= (size_t)163840;  // weight ring (Lin1Cfg::NS slots) + staging + bias vector (Lin1Cfg::lds_bytes)
 }
 void launch_linear1_ts(int hdp, int D, const Lin1Args &a, hipStream_t st) {
     switch ((hdp == 32 ? 0 : 4) + D / 128 - 1) {
