@@ -69,6 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="md17_bench", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU per step (0 = workload default)")
     ap.add_argument("--chunk", type=int, default=0, help="trajectories per pass inside the library (0 = default)")
+    ap.add_argument("--updates", type=int, default=0, help="profiling only: state updates per sampling call instead of the workload's (the line is marked "
+                                                           "config.reduced_updates; never a headline number).  PMC passes of the 1000-step peptide call need it")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch and stage-1 legs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event passes (rocprofv3 runs: every launch of the trace then belongs to a warm-up or timed sampling call)")
@@ -78,6 +80,9 @@ def parse_args(argv=None):
     ap.add_argument("--stub-compute", action="store_true",
                     help="launcher / collective plumbing test without a GPU: the sampling call is replaced by a trivial CPU op and the "
                          "line is marked data=stub (never a measurement)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="self-launched ranks (--gpus N without a launcher): stop all of them after this many seconds")
+    ap.add_argument("--rendezvous-timeout", type=float, default=180.0, help="seconds init_process_group (and every collective) may wait for the other ranks")
+    ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # launcher test: this rank exits with code 7 before the rendezvous
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)  # internal: one worker of the all-core CPU leg
     ap.add_argument("--cpu-threads", type=int, default=1, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -88,22 +93,53 @@ def parse_args(argv=None):
 
 
 def launch_ranks(args) -> int:
+    """Start one fresh child process per rank (this parent never touches a GPU), watch ALL of them, and fail fast: as soon as one rank
+    exits non-zero the others are stopped and the exit code is that rank's - a rank that dies before the rendezvous must not leave the
+    rest waiting for the collective library's own timeout.  Rank 0's stdout goes to a temporary file (nothing can block on a pipe)."""
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
-    if any(rcs) or not lines:
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n{out0 or ''}\n")
-        return next((rc for rc in rcs if rc), 1)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.monotonic() + args.launch_timeout
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            failed = f"no result after --launch-timeout {args.launch_timeout:.0f} s (ranks still running: {[r for r, rc in enumerate(rcs) if rc is None]})"
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out0.seek(0)
+    text = out0.read()
+    rcs = [p.returncode for p in procs]
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if failed or not lines:
+        sys.stderr.write(f"bench.py: {failed or 'rank 0 printed no result line'}; rank exit codes {rcs} (negative = stopped by the launcher)\n{text}\n")
+        return next((rc for rc in rcs if rc and rc > 0), 1)
     print(lines[-1])
     return 0
 
@@ -174,15 +210,22 @@ def run_rank(args) -> int:
     stub = args.stub_compute
     if args.backend == "gloo" and not stub:
         raise SystemExit("--backend gloo is only for --stub-compute (the product path has no CPU implementation)")
+    if stub and rank == args.stub_fail_rank:
+        sys.stderr.write(f"bench.py: rank {rank} fails on purpose (--stub-fail-rank)\n")
+        return 7
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tmo = datetime.timedelta(seconds=args.rendezvous_timeout)  # a rank that never arrives is an error after this long, not a hang
         if stub:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=tmo)
 
     kw, T, L, cond_idx, method, skw, default_b = WORKLOADS[args.workload]
     B = args.batch or default_b
+    if args.updates > 0:
+        skw = dict(skw, num_steps=args.updates + 1 if method == "ODE" else args.updates)
     n_evals = (skw["num_steps"] - 1) if method == "ODE" else skw["num_steps"]
     g = torch.Generator().manual_seed(1 + rank)
 
@@ -258,7 +301,13 @@ def run_rank(args) -> int:
     fence()
     dt = time.perf_counter() - t0
     gather_ms = None
+    per_rank = [{"rank": 0, "device": local_rank, "ms_per_step": dt / args.steps * 1e3}]
     if world > 1:
+        # every rank's own time: the step is the MAX over ranks, and the per-rank list shows a straggler GPU instead of hiding it in that max
+        mine = torch.tensor([dt, float(local_rank)], device=dev, dtype=torch.float64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "device": int(e[1].item()), "ms_per_step": float(e[0].item()) / args.steps * 1e3} for r, e in enumerate(every)]
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
@@ -296,8 +345,10 @@ def run_rank(args) -> int:
                    "mlp_ratio": kw["mlp_ratio"], "sampler": method, "state_updates": n_evals, "batch_per_gpu": B,
                    "global_batch": B * world, "parallelism": f"batch-shard x{world}, 1 gather to rank 0 per step",
                    # rank r draws the device noise of global elements [r * stride, (r + 1) * stride): the slice of the unsharded stream
-                   "noise_elem_stride_per_rank": B * T * L * kw["in_dim"]},
+                   "noise_elem_stride_per_rank": B * T * L * kw["in_dim"],
+                   **({"reduced_updates": True} if args.updates > 0 else {})},
         "rccl_ranks": rccl_ranks, "collective_backend": args.backend if world > 1 else None, "gather_ms": gather_ms,
+        "per_rank": per_rank,
     }
     if stub:
         out.update({"roofline": None, "cpu_baseline": None})
@@ -360,7 +411,7 @@ def run_rank(args) -> int:
     def committed_traffic(key):
         """HBM-side bytes per launch of kernel `key` from the newest committed PMC profile of this workload, scaled to this run's
         tokens per launch; not measured in this run (PMC counters need rocprofv3): the source file is named beside the number."""
-        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        for tf in traffic_files():
             try:
                 tj = json.load(open(tf))
                 if key and tj["workload"] == args.workload and key in tj:
@@ -368,6 +419,11 @@ def run_rank(args) -> int:
             except (OSError, KeyError, ValueError):
                 continue
         return None, None
+
+    def traffic_files():
+        """committed PMC-derived traffic files, newest round first: profiles/rNN_traffic.json (headline workload) and
+        profiles/rNN_traffic_<workload>.json"""
+        return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), key=lambda f: os.path.basename(f)[:3], reverse=True)
 
     how = "separate sampling call after the timed region, per-launch HIP events on the launch stream (one stream, nothing co-running)"
     traffic, traffic_src = committed_traffic({0: "linear1", 1: "linear2"}.get(args.profile_kernel))
@@ -388,20 +444,25 @@ def run_rank(args) -> int:
     # committed rocprofv3 PMC passes, derived by tools/traffic_from_pmc.py), which scales with the tokens of a step (weights are < 1 %), so
     # the per-token figure is scaled to this run's batch; time = this run's measured step.  As the step is cut into kernels, its HBM floor
     # is ABOVE its MFMA floor: the decomposition, not any single kernel, is HBM-bound.
-    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+    for tf in traffic_files():
         try:
             tj = json.load(open(tf))
             if tj.get("workload") != args.workload or "step" not in tj:
                 continue
-            step_bytes = tj["step"]["bytes_per_token"] * tok_total
+            # bytes per token and state update (the profile may have been taken with fewer updates per call: --updates), scaled to this run
+            per_tok_upd = tj["step"]["bytes_per_token"] / tj.get("state_updates", n_evals)
+            step_bytes = per_tok_upd * n_evals * tok_total
             step_flops = float(f_eval) * n_evals * B
             out["roofline_step"] = {
                 "bound": "hbm", "achieved": step_bytes / (step_ms * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
                 "frac": step_bytes / (step_ms * 1e-3) / 8e12, "frac_of_copy_rate": step_bytes / (step_ms * 1e-3) / 6.29e12,
-                "bytes_per_step": step_bytes, "bytes_per_token_per_step": tj["step"]["bytes_per_token"],
+                "bytes_per_step": step_bytes, "bytes_per_token_per_update": per_tok_upd,
                 "hbm_floor_ms": step_bytes / 8e12 * 1e3, "hbm_floor_ms_at_copy_rate": step_bytes / 6.29e12 * 1e3,
                 "mfma_floor_ms": step_flops / (PEAK_BF16_DENSE_TFLOPS * 1e12) * 1e3, "ms_per_step": step_ms,
-                "traffic_source": os.path.relpath(tf, ROOT), "derived_by": "tools/traffic_from_pmc.py (not measured in this run: PMC counters need rocprofv3)"}
+                "bytes_are": "profile-derived (PMC counters of the committed rocprofv3 profile named in traffic_source, taken at profile_commit), "
+                             "scaled to this run's tokens and updates; only the TIME is this run's",
+                "traffic_source": os.path.relpath(tf, ROOT), "profile_commit": tj.get("commit"), "profile_batch": tj.get("batch"),
+                "derived_by": "tools/traffic_from_pmc.py"}
             break
         except (OSError, KeyError, ValueError, TypeError):
             continue

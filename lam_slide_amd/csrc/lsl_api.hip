@@ -24,8 +24,8 @@
 #include "k_small.hip.h"
 #include "k_resident.hip.h"
 #ifdef LSL_EXPERIMENTS  // measured-and-rejected GEMM structures, built only by tools/build_experiments.sh (never in the product library)
-#include "experiments/k_gemm_pp.hip.h"
-#include "experiments/k_gemm_drain.hip.h"
+#include "k_gemm_pp.hip.h"        // tools/experiments/ (on the include path of tools/build_experiments.sh only)
+#include "k_gemm_drain.hip.h"
 #endif
 
 namespace {
@@ -827,6 +827,9 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     const bool lin1_ts = linear1_ts_ok(d.head_dim_pad, D, m->F1, m->HHD, n);
     const int npad = (n + 255) & ~255;
     const bool planes = qkv_planes_ok(d.head_dim_pad, D, d.heads, temporal ? T : L, temporal != 0, lin1_ts);
+    // head-major planes are addressed with 32-bit per-lane byte offsets over the whole q | k | v buffer (k_lin1.hip.h flush, k_attn.hip.h
+    // stream requests): a pass set larger than that through lsl_model_set_chunk / LSL_CHUNK_TRAJ is refused, never wrapped
+    if (planes && (unsigned long long)npad * 3ull * (unsigned)m->HHD * 2ull >= (1ull << 32)) return fail(-3, "pass too large for the q/k/v plane offsets (%d tokens: at most %llu with this model)", n, (unsigned long long)((1ull << 32) / (6ull * (unsigned)m->HHD)) - 256);
     if (lin1_ts) {
         const Lin1Args la{(const u16 *)bw.w1, ws.a, bw.b1, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                           ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->F1, n, m->HHD, d.mlp_dim,

@@ -658,13 +658,19 @@ class Sampler:
         out = model(x, t, **kw)
         tf = float(t.flatten()[0])
         vx, vm = tr.velocity_coeffs(tf)
-        if x.is_cuda and x.dtype == torch.float32 and out.dtype == torch.float32 and out.shape == x.shape:
+        v = None
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or out.requires_grad)  # (the library result carries no grad_fn)
+        if x.is_cuda and x.dtype == torch.float32 and out.dtype == torch.float32 and out.shape == x.shape and not needs_grad:
             # one library launch instead of three element-wise kernels; the same two rounded products and their rounded sum
-            ops = self._rk_ops.get(x.device)
-            if ops is None:
-                ops = self._rk_ops[x.device] = _RkOps(x)
-            v = ops.lincomb([(vx, x), (vm, out)])
-        else:
+            try:
+                ops = self._rk_ops.get(x.device)
+                if ops is None:
+                    ops = self._rk_ops[x.device] = _RkOps(x)
+                v = ops.lincomb([(vx, x), (vm, out)])
+            except RuntimeError:  # no library (an arbitrary callable on a GPU needs none): the torch expression below, same values
+                if x.device in self._rk_ops:
+                    raise
+        if v is None:
             v = vx * x + vm * out
         assert v.shape == x.shape, "Output shape from ODE solver must match input shape"
         return v, out

@@ -318,3 +318,66 @@ def test_override_yaml_runs_the_fused_path_on_gpu(path):
     err = rel_l2(got.cpu(), want)
     from conftest import parity
     parity(f"dropin.{'/'.join(path.split(os.sep)[-2:])}", err, 1e-3)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+def test_install_on_the_real_reference_modules_and_real_lightning_sample(golden):
+    """The drop-in against the reference's REAL modules (nothing faked but Lightning / Hydra themselves, tools/ref_env.py): the real
+    `src.modules.transport` package and `models/composites/lightning_base.py` are imported, `install()` rebinds `Sampler` on those module
+    objects, a real `Transport` passes `as_transport`, and `SecondStageCondLightningBase.sample` (lightning_base.py:217-238) - unchanged,
+    on the real second_stage/md17.py Wrapper built by its own __init__ from the reference YAML - gives the F9 fixture with this package's
+    Sampler behind the module-level name (generic per-step loop around the reference backbone on the CPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_env
+
+    import lam_slide_amd
+    from lam_slide_amd import dropin
+    from lam_slide_amd.transport import as_transport
+    dropin.uninstall()
+    ns = ref_env.setup()
+    ref_sampler = ns.transport.Sampler
+    assert ns.lightning_base.Sampler is ref_sampler and ref_sampler is not lam_slide_amd.Sampler
+    assert not hasattr(ns.transport_pkg, "Sampler")  # (the package __init__ re-exports the Transport names only)
+    try:
+        # the trigger a config override provides: the overridden transport factory is constructed (LSL_NO_INSTALL unset)
+        lam_slide_amd.CreateTransport("GVP", "data")
+        assert ns.lightning_base.Sampler is lam_slide_amd.Sampler and ns.transport.Sampler is lam_slide_amd.Sampler
+        assert dropin.original_sampler() is ref_sampler
+        # a REAL reference Transport object (what `instantiate(transport)()` of an un-overridden config returns)
+        real_tr = ns.transport_pkg.CreateTransport("GVP", "data")()
+        assert type(real_tr).__module__ == "src.modules.transport.transport"
+        mine = as_transport(real_tr)
+        assert mine.path_type is lam_slide_amd.PathType.GVP and mine.model_type is lam_slide_amd.ModelType.DATA
+        assert (mine.train_eps, mine.sample_eps) == (real_tr.train_eps, real_tr.sample_eps) == (1e-3, 1e-3)
+        assert mine.check_interval(mine.train_eps, mine.sample_eps, sde=False, eval=True) == real_tr.check_interval(
+            real_tr.train_eps, real_tr.sample_eps, sde=False, eval=True)
+        # the real LightningModule, reference backbone + reference transport factory, Sampler = this package's
+        f = golden("f9_sample.npz")
+        first, first_cls = ref_env.build_first_stage(ns)
+        w = ref_env.build_wrapper(ns, "src.models.components.latent.latent_si_v31.LatentSIV3", "src.modules.transport.CreateTransport", first, first_cls)
+        w.eval()
+        assert type(w.si).__module__ == "src.modules.transport.transport"
+        w.backbone.load_state_dict(f.group("backbone"))
+        first.backbone.load_state_dict(f.group("stage1"))
+        batch = {"pos": f["x"], "entities": f["entities"], "attention_mask": f["attention_mask"]}
+        with ref_env.fixed_randn_like(f["noise"]):
+            pos = w.sample(dict(batch))["pos"]
+        assert rel_l2(pos, f["pos"]) < 2e-6
+        # ... and with the override `_target_`s: the transport factory of this package inside the real Wrapper (CPU: generic loop again)
+        w2 = ref_env.build_wrapper(ns, "src.models.components.latent.latent_si_v31.LatentSIV3", "lam_slide_amd.CreateTransport", first, first_cls)
+        w2.eval()
+        assert isinstance(w2.si, lam_slide_amd.Transport)
+        w2.backbone.load_state_dict(f.group("backbone"))
+        with ref_env.fixed_randn_like(f["noise"]):
+            pos2 = w2.sample(dict(batch))["pos"]
+        assert rel_l2(pos2, f["pos"]) < 2e-6
+        # the override backbone constructs inside the real Wrapper and takes the reference state dict (it runs on the GPU only)
+        w3 = ref_env.build_wrapper(ns, "lam_slide_amd.LatentSIV3", "lam_slide_amd.CreateTransport", first, first_cls)
+        assert isinstance(w3.backbone, lam_slide_amd.LatentSIV3)
+        w3.backbone.load_state_dict(f.group("backbone"))
+        with pytest.raises(RuntimeError):
+            with ref_env.fixed_randn_like(f["noise"]):
+                w3.sample(dict(batch))   # CPU tensors: the product path refuses, it does not fall back
+    finally:
+        dropin.uninstall()
+    assert ns.lightning_base.Sampler is ref_sampler

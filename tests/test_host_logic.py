@@ -342,9 +342,32 @@ def test_bench_self_launches_its_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo" and out["steps"] == 2
     assert out["config"]["global_batch"] == 6 and out["gather_ms"] is not None and out["value"] > 0 and out["scaling"] == "weak"
     assert "stub" in out["data"]
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["ms_per_step"] > 0 for r in out["per_rank"])  # a straggler would show here
+    assert max(r["ms_per_step"] for r in out["per_rank"]) == pytest.approx(out["ms_per_step"], rel=1e-9)       # the step is the max over ranks
     # the product path refuses gloo / CPU
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--no-cpu"], env=env, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies_before_the_rendezvous():
+    """One of four self-launched ranks exits (code 7) before init_process_group: the launcher must stop the other three - which are
+    waiting in the rendezvous - and return that code within seconds, not after the collective library's timeout."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    t0 = time.monotonic()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0", "--backend", "gloo",
+                          "--stub-compute", "--stub-fail-rank", "2", "--batch", "2", "--no-cpu", "--rendezvous-timeout", "600"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    took = time.monotonic() - t0
+    assert res.returncode == 7, (res.returncode, res.stderr)
+    assert "rank 2 exited with code 7" in res.stderr and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert took < 120, took  # (process start-up + torch import dominate; the rendezvous timeout above is 600 s)
+    # and a launch that never finishes is stopped by --launch-timeout
+    res = subprocess.run([sys.executable, "-c", "import sys; sys.argv=['bench.py','--gpus','2','--launch-timeout','0.5']; import bench; a=bench.parse_args(); "
+                          "import subprocess as sp; real=sp.Popen; bench.subprocess.Popen=lambda *x, **k: real([sys.executable,'-c','import time; time.sleep(60)']); "
+                          "sys.exit(bench.launch_ranks(a))"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 1 and "no result after --launch-timeout" in res.stderr, res.stderr
 
 
 @pytest.mark.parametrize("workload,batch,stride", [("nba", 1024, 1024 * 20 * 8 * 32), ("peptide", 8, 8 * 1000 * 2 * 96)])

@@ -138,3 +138,22 @@ def test_f8_decoder_query_splitter_restatement(golden):
     d = golden("f8_decode_split.npz")
     pos = harness.decode(d.group("p"), harness.DecoderShape(num_block_cross=1, act="gelu_tanh"), d["z"], d["entities"])
     assert rel_l2(pos, d["pos"]) < 2e-6
+
+
+def test_f9_real_lightning_module_sample_chain(golden):
+    """F9 = the reference's real LightningModule (second_stage/md17.py Wrapper, lightning_base.py sample / prepare_batch /
+    setup_conditioning, executed unchanged in the build container by tools/make_fixtures.py f9): stage-1 inputs -> encode -> conditioning
+    -> 5 Euler updates from a fixed initial noise -> decode.  The oracle chain reproduces every stage."""
+    f = golden("f9_sample.npz")
+    B, T, A, L, c0, c1, n = (int(v) for v in f["meta"])
+    s1, sd = f.group("stage1"), f.group("backbone")
+    flat = lambda t: t.reshape(B * T, *t.shape[2:])  # noqa: E731
+    lat = harness.encode(s1, harness.EncoderShape(num_latents=L), flat(f["x"]), flat(f["entities"]), flat(f["attention_mask"])).reshape(B, T, L, 32)
+    assert rel_l2(lat, f["latents"]) < 2e-6
+    xc, mask = harness.setup_conditioning(lat, (c0, c1), True)
+    assert torch.equal(mask, f["mask"]) and rel_l2(xc, f["x_cond"]) < 2e-6
+    sh = latent_net.NetShape(depth=2, in_dim=32, hidden_size=64, mlp_ratio=2, num_heads=4)
+    final = harness.sample_latents(sd, sh, otr.Transport("GVP", "data"), f["noise"], xc, mask, None, "ODE", {"sampling_method": "euler", "num_steps": n})
+    assert rel_l2(final, f["final"]) < 5e-6
+    pos = harness.decode(s1, harness.DecoderShape(), flat(final), flat(f["entities"])).reshape(f["pos"].shape)
+    assert rel_l2(pos, f["pos"]) < 5e-6

@@ -14,7 +14,7 @@
 // Shapes: full tiles only (F % 256 == 0, N % 128 == 0: the epilogue stores are unconditional, which keeps the number of vector
 // memory operations per piece fixed); K % 64 == 0.  Other shapes use the plain kernels.
 #pragma once
-#include "../k_gemm.hip.h"
+#include "k_gemm.hip.h"  // lam_slide_amd/csrc (the including translation unit's directory)
 
 template <class Epi>
 struct GemmDrainCfg {

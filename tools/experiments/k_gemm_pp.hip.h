@@ -21,7 +21,7 @@
 // come BEFORE the first prefetch of the next tile in program order, so at the start of a MAIN phase the queue ends with
 // exactly the NS-1 prefetched k-tiles and the usual counted wait applies.
 #pragma once
-#include "../k_gemm.hip.h"
+#include "k_gemm.hip.h"  // lam_slide_amd/csrc (the including translation unit's directory)
 
 template <int BK, int NS, class Epi>
 struct GemmPPCfg {

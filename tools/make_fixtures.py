@@ -16,6 +16,9 @@ Fixture families:
   f6_decode.npz     frozen stage-1 decode of latents -> positions (MD17 decoder shape, seeded weights)
   f7_encode.npz     frozen stage-1 Encoder + quant with a ragged entity mask (MD17 encoder shape, 48 latents)
   f8_decode_split.npz  DecoderQuerySplitter (peptide decoder: 1x1-conv latent extender), one latent<-query cross block, tanh GELU
+  f9_sample.npz     the reference's REAL LightningModule (second_stage/md17.py Wrapper built by its own __init__ from the reference YAML,
+                    lightning_base.py sample / prepare_batch / setup_conditioning unchanged; tools/ref_env.py supplies the Lightning / Hydra
+                    stand-ins): stage-1 inputs -> encode -> conditioning -> 5 Euler updates -> decode, with the initial noise fixed
 """
 import ast
 import os
@@ -438,7 +441,63 @@ def f8():
     npz("f8_decode_split.npz", p=p, z=z, entities=ent, pos=pos)
 
 
+# ------------------------------------------------------------------------------------------- F9
+def f9():
+    """SecondStageCondLightningBase.sample (lightning_base.py:217-238) executed UNCHANGED on the reference's real second-stage Wrapper.
+    Run twice: with the reference's own Sampler, and after lam_slide_amd.install() (the module-level Sampler rebound: this package's
+    Sampler then steps the reference backbone through its generic loop) - the two must agree; the first is the fixture."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_env
+    import lam_slide_amd
+    from lam_slide_amd import dropin
+    dropin.uninstall()
+    ns = ref_env.setup()
+    F = ref_env.F9
+    first, first_cls = ref_env.build_first_stage(ns)
+    w = ref_env.build_wrapper(ns, "src.models.components.latent.latent_si_v31.LatentSIV3", "src.modules.transport.CreateTransport", first, first_cls)
+    w.eval()
+    assert ns.lightning_base.Sampler is ns.transport.Sampler and ns.lightning_base.Sampler is not lam_slide_amd.Sampler
+    batch = ref_env.f9_batch()
+    noise = torch.randn(F["B"], F["T"], F["L"], 32, generator=torch.Generator().manual_seed(24))
+    seen = {}
+    real_decode = w.decode
+
+    def tap(latents, entities):
+        seen["final"] = latents.clone()
+        return real_decode(latents, entities)
+
+    w.decode = tap
+    with ref_env.fixed_randn_like(noise):
+        ref_pos = w.sample(dict(batch))["pos"]
+    final_ref = seen["final"]
+    enc_lat = w.encode(dict(batch))
+    xc, mask = w.setup_conditioning(enc_lat)
+    # the same call with this package's Sampler behind the reference's module-level name
+    done = dropin.install(force=True)
+    assert "src.models.composites.lightning_base.Sampler" in done and ns.lightning_base.Sampler is lam_slide_amd.Sampler
+    with ref_env.fixed_randn_like(noise):
+        mine_pos = w.sample(dict(batch))["pos"]
+    dropin.uninstall()
+    e_swap = rel(mine_pos, ref_pos)
+    # oracle chain on the same inputs
+    sd = {k: v.clone() for k, v in w.backbone.state_dict().items()}
+    s1 = {k: v.clone() for k, v in first.backbone.state_dict().items()}
+    flat = lambda t: t.reshape(F["B"] * F["T"], *t.shape[2:])  # noqa: E731
+    es = harness.EncoderShape(num_latents=F["L"])
+    o_lat = harness.encode(s1, es, flat(batch["pos"]), flat(batch["entities"]), flat(batch["attention_mask"])).reshape(F["B"], F["T"], F["L"], 32)
+    oxc, omask = harness.setup_conditioning(o_lat, tuple(F["cond_idx"]), True)
+    sh = latent_net.NetShape(**F["backbone"])
+    o_final = harness.sample_latents(sd, sh, otr.Transport("GVP", "data"), noise, oxc, omask, None, "ODE", {"sampling_method": "euler", "num_steps": F["num_steps"]})
+    o_pos = harness.decode(s1, harness.DecoderShape(), flat(o_final), flat(batch["entities"])).reshape(ref_pos.shape)
+    print(f"F9 real LightningModule: install() swap rel {e_swap:.2e}; oracle encode {rel(o_lat, enc_lat):.2e} latents {rel(o_final, final_ref.reshape(o_final.shape)):.2e} "
+          f"positions {rel(o_pos, ref_pos):.2e}")
+    assert e_swap < 2e-6 and rel(o_pos, ref_pos) < 1e-5 and torch.equal(omask, mask)
+    npz("f9_sample.npz", backbone=sd, stage1=s1, x=batch["pos"], entities=batch["entities"], attention_mask=batch["attention_mask"], noise=noise,
+        latents=enc_lat, x_cond=xc, mask=mask, final=final_ref.reshape(o_final.shape), pos=ref_pos,
+        meta=np.array([F["B"], F["T"], F["A"], F["L"], F["cond_idx"][0], F["cond_idx"][1], F["num_steps"]]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9"]
     for w in which:
         globals()[w]()

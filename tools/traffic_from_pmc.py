@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM-side traffic of one sampling step from a rocprofv3 profile of bench.py (tools/gpu_profile.sh -> gpurun_out/prof_<tag>.summary.txt).
+"""HBM-side traffic of one sampling step from a rocprofv3 profile of bench.py (tools/gpu.sh prof | profile -> gpurun_out/prof_<tag>.summary.txt).
 
     python tools/traffic_from_pmc.py gpurun_out/prof_r04.summary.txt --workload md17_bench --batch 32 --calls 13 -o profiles/r04_traffic.json
 
@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--tokens-per-traj", type=int, default=30 * 256)
     ap.add_argument("--calls", type=int, required=True, help="sampling calls in the kernel-trace run")
+    ap.add_argument("--updates", type=int, default=0, help="state updates per sampling call of the profiled command (bench.py --updates; 0 = not recorded)")
+    ap.add_argument("--commit", default="", help="git commit of the library the profile was taken with (recorded; bench.py names it beside the derived figures)")
     ap.add_argument("--flops-per-step", type=float, default=0.0, help="algorithmic FLOPs of one step (bench.py prints whole_path_tflops * s)")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
@@ -69,6 +71,10 @@ def main():
             kernels[name]["note"] = f"trace calls {st['calls']} != {n_f} launches x {a.calls} sampling calls"
     out = {"note": __doc__.split("\n\n")[2].replace("\n", " "), "source": os.path.relpath(a.summary), "workload": a.workload, "batch": a.batch,
            "tokens_per_step": a.batch * a.tokens_per_traj, "kernels": kernels}
+    if a.updates:
+        out["state_updates"] = a.updates
+    if a.commit:
+        out["commit"] = a.commit
     # per class (what bench.py's roofline / roofline2 look up): the kernel of the class with the most bytes per step
     for cls, rx in CLASSES:
         ks = [(v["bytes_per_step"], k) for k, v in kernels.items() if re.search(rx, k)]
