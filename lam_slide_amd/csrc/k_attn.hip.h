@@ -363,44 +363,72 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
 // 3 x slower); q / k / v of spatial sub-blocks come as head-major planes (AttnArgs::planes), where a unit's rows are one contiguous run -
 // as token-major rows every 64-byte row piece drags a whole 128-byte line through the L1 miss path; units are dealt round-robin in
 // XCD-contiguous order so that heads sharing lines meet in one L2.
-template <int HDP, bool LONG>
+#ifndef LSL_ATTN_XL_UNROLL
+#define LSL_ATTN_XL_UNROLL 1
+#endif
+template <int HDP, bool LONG, bool XL = false, bool ONES = false>
 __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
+    static_assert(LONG || !XL, "chunked keys / grouped queries exist for the LONG form only");
+    static_assert(!ONES || (XL && HDP == 32), "the denominator column needs a padded head (head_dim 24 of 32); instantiated for the chunked form");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = HDP * 2, CPR = ROWB / 16, KS = HDP / 16;
-    constexpr int KVB = 256 * ROWB, BUF = 2 * KVB;  // K (or V) image of a unit; K | V
-    constexpr int NI = BUF / 1024, IPW = NI / 8;    // LDS-DMA instructions per unit / per wave
+    constexpr int KVB = 256 * ROWB, BUF = 2 * KVB;  // K (or V) image of a stage; K | V
+    constexpr int NI = BUF / 1024, IPW = NI / 8;    // LDS-DMA instructions per stage / per wave
     constexpr int RPI = 1024 / ROWB;                // image rows per instruction
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hf = lane >> 5;
-    const int S = a.S, nkt = LONG ? (S + 31) >> 5 : 1;
+    const int S = a.S;
+    // LONG axes of any length (round 5): the keys of a (sequence, head) go through the two images in CHUNKS of 256 rows, the queries in GROUPS
+    // of 8 tiles (one per wave); a unit = (sequence, head, query group) walks its NC key chunks as NC stages, the accumulators stay in
+    // registers across them - with the unshifted softmax below there is nothing to rescale between chunks.  S <= 256: one chunk, one group,
+    // i.e. exactly the round-4 kernel (same instruction order per tile, same bits).  SHORT: one stage per unit.
+    // (XL = false: S <= 256, both counts are the compile-time constant 1 and the code below folds to the round-4 kernel)
+    const int NC = XL ? (S + 255) >> 8 : 1;                         // key chunks
+    const int QG = XL ? (((S + 31) >> 5) + 7) >> 3 : 1;             // query groups
+    const int rows_last = S - 256 * (NC - 1);                       // key rows of the last chunk (1 .. 256)
+    const int nkt_last = LONG ? (rows_last + 31) >> 5 : 1;          // key tiles of the last chunk
+    const int qrows_last = S - 256 * (QG - 1);                      // query rows of the last group
     const int hgroups = a.H >> 3;
-    const long n_units = LONG ? (long)a.n_seq * a.H : (long)a.n_seq * hgroups;
-    // units are dealt round-robin over the workgroups in XCD-contiguous order: neighbouring (sequence, head) units - whose 64-byte row pieces
-    // share 128-byte lines - run at the same time on one XCD and meet in its L2 (with a contiguous range per workgroup the second head of a
-    // line came one unit-time later, after the line had left the L2: FETCH_SIZE 1.38 GB per launch for 0.755 GB of rows)
+    const long n_units = LONG ? (long)a.n_seq * a.H * QG : (long)a.n_seq * hgroups;
+    // units are dealt round-robin over the workgroups in XCD-contiguous order: neighbouring units - the query groups of one (sequence, head),
+    // which read the same keys, and neighbouring heads, whose 64-byte row pieces share 128-byte lines - run at the same time on one XCD and
+    // meet in its L2 (with a contiguous range per workgroup the second head of a line came one unit-time later, after the line had left the
+    // L2: FETCH_SIZE 1.38 GB per launch for 0.755 GB of rows)
     const long ustep = gridDim.x, u0 = xcd_remap(blockIdx.x, gridDim.x), u1 = n_units;
     if (u0 >= u1) return;  // (uniform)
-    const bool has_tile = !LONG || wave < nkt;  // (uniform) LONG: wave w = query tile w
     const unsigned rs = 3u * a.HHD;
     const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))(smem);
     const bool planes = LONG && a.planes;  // (uniform) plane layout: positions of a sequence are consecutive tokens (pos_stride 1)
+    // padded heads (hd = 24 of HDP = 32, peptide): channel hd of every staged V row := 1.0, so that row hd of O^T = V^T P^T IS the softmax
+    // denominator (k_attention_rows has the argument): 4 instead of 6 MFMAs per tile pair
+    constexpr bool ones_col = ONES;  // (the host selects the instance: head_dim == 24; acc_row(12, 0) == 24)
 
-    // per-lane parts of the addresses (constant over the units)
-    unsigned voff_kv[IPW];
+    // per-lane parts of the K / V request addresses: the part that does not depend on the key row, and the row R (0 .. 255) of the image the
+    // lane fills; the row's position term is added per request (rows past the end of the sequence - last chunk only - clamped)
+    unsigned cst_kv[IPW];
+    int row_kv[IPW];
+    const unsigned pos_bytes = planes ? 2u * HDP : 2u * a.pos_stride * rs;  // bytes between consecutive positions of a sequence
 #pragma unroll
     for (int k = 0; k < IPW; ++k) {
         const int i = wave * IPW + k, kv = i / (NI / 2), ii = i % (NI / 2);
         const int R = RPI * ii + lane / CPR, slot = lane % CPR;
         const int chunk = kv == 0 ? slot ^ (HDP == 32 ? (R >> 2) & 3 : (R >> 3) & 1) : slot;
-        const int item_local = LONG ? 0 : R >> 5, pos = min(LONG ? R : R & 31, S - 1);
-        voff_kv[k] = planes ? 2u * (((unsigned)(1 + kv) * a.H * a.npad + (unsigned)pos) * HDP + chunk * 8)
-                            : 2u * ((unsigned)pos * a.pos_stride * rs + (1 + kv) * a.HHD + item_local * HDP + chunk * 8);
+        const int item_local = LONG ? 0 : R >> 5;
+        row_kv[k] = LONG ? R : R & 31;
+        cst_kv[k] = planes ? 2u * ((unsigned)(1 + kv) * a.H * a.npad * HDP + chunk * 8) : 2u * ((1 + kv) * a.HHD + item_local * HDP + chunk * 8);
+        if (!XL) cst_kv[k] += pos_bytes * (unsigned)min(row_kv[k], S - 1);
     }
 
-    auto unit_tok0 = [&](long u, int &head0) __attribute__((always_inline)) {
-        const int seq = LONG ? (int)(u / a.H) : (int)(u / hgroups);
-        head0 = LONG ? (int)(u % a.H) : 8 * (int)(u % hgroups);
+    auto unit_tok0 = [&](long u, int &head0, int &qg) __attribute__((always_inline)) {
+        long sh = u;
+        qg = 0;
+        if (LONG && QG > 1) {  // (uniform)
+            sh = u / QG;
+            qg = (int)(u - sh * QG);
+        }
+        const int seq = LONG ? (int)(sh / a.H) : (int)(sh / hgroups);
+        head0 = LONG ? (int)(sh % a.H) : 8 * (int)(sh % hgroups);
         return (size_t)(seq / a.inner) * a.outer_stride + (seq % a.inner);
     };
     // (wave-uniform by construction; the readfirstlanes make it provable for the "s" operands of the asm statements)
@@ -415,40 +443,60 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
     // back-edge and in front of the wait - NaNs; and once accumulator registers are named in asm it allocates the same ones itself.)
     constexpr int QIMG = 32 * ROWB, QPW = QIMG / 1024 > 0 ? QIMG / 1024 : 1;  // bytes and LDS-DMA instructions of a query tile
     char *const qimg = smem + 2 * BUF + wave * QIMG;
-    unsigned voff_qt[QPW];
+    unsigned cst_qt[QPW];  // (as for K / V: row-independent part; the tile row is RPI k + lane / CPR)
 #pragma unroll
     for (int k = 0; k < QPW; ++k) {
         const int R = RPI * k + lane / CPR, slot = lane % CPR;  // tile row, 16-byte slot
         const int chunk = slot ^ (HDP == 32 ? (R >> 2) & 3 : (R >> 3) & 1);
-        const int pos = min((LONG ? 32 * wave : 0) + R, S - 1);
-        voff_qt[k] = planes ? 2u * ((unsigned)pos * HDP + chunk * 8) : 2u * ((unsigned)pos * a.pos_stride * rs + (LONG ? 0 : wave * HDP) + chunk * 8);
+        cst_qt[k] = 2u * ((LONG ? 0 : wave * HDP) + chunk * 8);
+        if (!XL) cst_qt[k] += pos_bytes * (unsigned)min((LONG ? 32 * wave : 0) + R, S - 1);
     }
-    auto request = [&](long u, int SET) __attribute__((always_inline)) {  // SET: K | V image of the unit being requested
-        int head0;
-        const size_t tok0 = unit_tok0(u, head0);
+    // K | V rows of key chunk c of unit u -> image SET
+    auto request_kv = [&](long u, int c, int SET) __attribute__((always_inline)) {
+        int head0, qg;
+        const size_t tok0 = unit_tok0(u, head0, qg) + (size_t)(256 * c) * a.pos_stride;
         const char *base = uni_ptr(reinterpret_cast<const char *>(a.qkv) +
                                    (planes ? 2 * (((size_t)head0 * a.npad + tok0) * HDP) : 2 * (tok0 * rs + (size_t)head0 * HDP)));
+        const bool last = c == NC - 1;  // (uniform)
 #pragma unroll
         for (int k = 0; k < IPW; ++k) {
             const int i = wave * IPW + k;
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + SET * BUF + (i / (NI / 2)) * KVB + (i % (NI / 2)) * 1024);
-            const unsigned vk = voff_kv[k];
+            // (!XL: one stage per unit, the clamped position was folded into cst_kv once)
+            const unsigned vk = XL ? cst_kv[k] + pos_bytes * (unsigned)min(row_kv[k], (last ? rows_last : 256) - 1) : cst_kv[k];
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vk), "s"(base), "s"(dst) : "memory");
         }
+    };
+    // the wave's query tile of unit u -> its private image
+    auto request_q = [&](long u) __attribute__((always_inline)) {
+        int head0, qg;
+        const size_t tok0 = unit_tok0(u, head0, qg) + (size_t)(256 * qg) * a.pos_stride;
+        const char *base = uni_ptr(reinterpret_cast<const char *>(a.qkv) +
+                                   (planes ? 2 * (((size_t)head0 * a.npad + tok0) * HDP) : 2 * (tok0 * rs + (size_t)head0 * HDP)));
+        const bool last = qg == QG - 1;  // (uniform)
 #pragma unroll
         for (int k = 0; k < QPW; ++k) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + 2 * BUF + wave * QIMG + k * 1024);
-            const unsigned vq = voff_qt[k];  // (an odr-use: a generic lambda does not capture a variable that only appears as an asm operand)
+            const int R = RPI * k + lane / CPR, lim = (LONG ? (last ? qrows_last : 256) : S) - 1;
+            const unsigned vq = XL ? cst_qt[k] + pos_bytes * (unsigned)max(min(32 * wave + R, lim), 0) : cst_qt[k];
             if (QIMG >= 1024 || lane < QIMG / 16)
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vq), "s"(base), "s"(dst) : "memory");
+        }
+    };
+    // ones_col: the V rows a wave requested itself (waves 4 - 7: rows 64 (w - 4) .. + 63 of the image), patched once they have landed and
+    // before the stage's barrier
+    auto patch_ones = [&](int SET) __attribute__((always_inline)) {
+        if (ones_col && wave >= 4) {
+            *reinterpret_cast<u16 *>(smem + SET * BUF + KVB + (64 * (wave - 4) + lane) * ROWB + 2 * a.hd) = (u16)0x3F80;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
 
     const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, grp = lane >> 4;
     const int v_off = (4 * (grp >> 1) + gq) * ROWB + ((HDP == 32 ? (grp & 1) * 16 : 0) + 4 * gp) * 2;
     const int krow0 = LONG ? 0 : 32 * wave;  // first image row of this wave's keys
-    const bool ragged = (S & 31) != 0;       // (uniform) the last key tile is partial
-    const int last_rows = S - 32 * (nkt - 1);
+    const bool ragged = ((LONG ? rows_last : S) & 31) != 0;  // (uniform) the last key tile of the last chunk is partial
+    const int last_rows = (LONG ? rows_last : S) - 32 * (nkt_last - 1);
     f32x16 zero;
 #pragma unroll
     for (int e = 0; e < 16; ++e) zero[e] = 0.0f;
@@ -460,22 +508,22 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
     // stores clog the in-order vector-memory pipe in front of the next unit's requests: measured 0.78 ms per launch with streaming stores,
     // 0.27 with plain ones, 0.205 with no store at all (profiles/r04_experiments.txt).
     constexpr int OPW = QPW;  // output store instructions per wave and unit
-    unsigned voff_zr[OPW];
-    bool zr_ok[OPW];
+    unsigned voff_zr[OPW];    // (relative to the unit's first query row)
 #pragma unroll
     for (int k = 0; k < OPW; ++k) {
         const int R = RPI * k + lane / CPR, chunk = lane % CPR;
         const int pos = (LONG ? 32 * wave : 0) + R;
-        zr_ok[k] = pos < S && (QIMG >= 1024 || lane < QIMG / 16);
-        voff_zr[k] = 2u * ((unsigned)min(pos, S - 1) * a.pos_stride * a.zw + (LONG ? 0 : wave * HDP) + chunk * 8);
+        voff_zr[k] = 2u * ((unsigned)pos * a.pos_stride * a.zw + (LONG ? 0 : wave * HDP) + chunk * 8);
     }
     auto read_q = [&](bf16x8 (&q)[KS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) q[s2] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qimg + k_swz<HDP>(r, 2 * s2 + hf)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in registers before anything else is written to the image
     };
-    request(u0, 0);
+    request_kv(u0, 0, 0);
+    request_q(u0);
     wait_vmcnt<0>();
+    patch_ones(0);
     bf16x8 qn[KS];
     read_q(qn);
     int buf = 0;
@@ -483,93 +531,132 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         bf16x8 qf[KS];
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) qf[s2] = qn[s2];
-        __builtin_amdgcn_s_barrier();  // every wave's rows of this unit have landed (each waited for its own); every wave has left the other image
-        asm volatile("" ::: "memory");
-        const bool more = u + ustep < u1;  // (uniform)
-        if (more) request(u + ustep, buf ^ 1);
-        f32x16 o = zero;
-        float inv_l = 0.0f;
-        if (has_tile) {
-            const char *Ks = smem + buf * BUF, *Vs = Ks + KVB;
-            auto scores = [&](int kt, const f32x16 &init) __attribute__((always_inline)) {
-                f32x16 t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(krow0 + kt * 32 + r, hf))), qf[0], init);
-                if (KS == 2)
-                    t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(krow0 + kt * 32 + r, 2 + hf))), qf[KS - 1], t);
-                if (kt == nkt - 1 && ragged) {  // wave-uniform; only the last tile can hold clamped rows past the sequence: they do not take part
+        int head0, qg;
+        const size_t tok0 = unit_tok0(u, head0, qg);
+        const bool last_g = qg == QG - 1;                                     // (uniform)
+        const bool has_tile = !LONG || 256 * qg + 32 * wave < S;              // (uniform) LONG: wave w = query tile w of the group
+        const bool more = u + ustep < u1;                                     // (uniform)
+        // softmax bound of this wave's queries (see above): decided once per unit
+        float mx = -INFINITY;
+        bool shifted = false;
+        if (has_tile && a.kmax2) {
+            float qq = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if (acc_row(e, hf) >= last_rows) t[e] = -INFINITY;
+            for (int s2 = 0; s2 < KS; ++s2) {
+                const u32x4 w = __builtin_bit_cast(u32x4, qf[s2]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+                    qq = fmaf(lo, lo, fmaf(hi, hi, qq));
                 }
-                return t;
-            };
-            float mx = -INFINITY;
-            bool shifted = false;
-            if (a.kmax2) {
-                float qq = 0.0f;
-#pragma unroll
-                for (int s2 = 0; s2 < KS; ++s2) {
-                    const u32x4 w = __builtin_bit_cast(u32x4, qf[s2]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
-                        qq = fmaf(lo, lo, fmaf(hi, hi, qq));
-                    }
-                }
-                qq += xhalf(qq);
-                const float m = sqrtf(qq * kmax2) * 1.02f;
-                shifted = __ballot(m > 60.0f) == 0;  // (wave-uniform)
-                if (shifted) mx = m;
             }
-            if (!shifted) {
-                for (int kt = 0; kt < nkt; ++kt) {
-                    const f32x16 t = scores(kt, zero);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[e]);
-                }
-                mx = fmaxf(mx, xhalf(mx));
-            }
-            // Shifted by the bound (the usual case): NO shift is applied at all.  |s_ij| <= m_i <= 60, so exp2(s_ij) lies in [2^-60, 2^60]: it
-            // fits fp32 and bf16 (8 exponent bits) as it is, the sums over <= 256 keys stay below 2^68, and the common factor 2^m_i cancels in
-            // O / l exactly as a shift would.  The score MFMA then starts from the constant 0 (an inline operand) instead of a 16-register
-            // preset that hipcc copies into the accumulator in front of every tile (16 of the 60 vector instructions per tile pair that the
-            // counters showed).  Exact-maximum fallback: the preset form.
-            f32x16 negmx;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) negmx[e] = shifted ? 0.0f : -mx;
-            const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // eight bf16 1.0
-            f32x16 lsum = zero;
-            auto tile = [&](int kt, const f32x16 &t) __attribute__((always_inline)) {
-                float p[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(t[e]);
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    u32x4 pw = {pack2(p[8 * s2], p[8 * s2 + 1]), pack2(p[8 * s2 + 2], p[8 * s2 + 3]),
-                                pack2(p[8 * s2 + 4], p[8 * s2 + 5]), pack2(p[8 * s2 + 6], p[8 * s2 + 7])};
-                    const char *vb = Vs + (krow0 + kt * 32 + 16 * s2) * ROWB + v_off;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb));
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb + 8 * ROWB));
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o = mfma32(__builtin_bit_cast(bf16x8, vv), as_bf16x8(pw), o);
-                    lsum = mfma32(as_bf16x8(ones_w), as_bf16x8(pw), lsum);  // every row = sum over this tile's keys, column = query
-                }
-            };
-            if (shifted) {
-                if (!LONG) tile(0, scores(0, zero));
-                else {
-#pragma unroll 2
-                    for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, zero));  // (fully unrolled, hipcc hoists every fragment address and spills)
-                }
-            } else {
-                for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, negmx));
-            }
-            inv_l = 1.0f / lsum[0];
+            qq += xhalf(qq);
+            const float m = sqrtf(qq * kmax2) * 1.02f;
+            shifted = __ballot(m > 60.0f) == 0;  // (wave-uniform)
+            if (shifted) mx = m;
         }
-        wait_vmcnt<0>();  // the next unit's rows and query tile (requested a whole unit ago)
-        asm volatile("" ::: "memory");
+        f32x16 o = zero, lsum = zero;
+#pragma unroll 1
+        for (int c = 0; c < NC; ++c) {  // stage (u, c)
+            __builtin_amdgcn_s_barrier();  // every wave's rows of this stage have landed (each waited for its own); every wave has left the other image
+            asm volatile("" ::: "memory");
+            const bool last_c = c == NC - 1;  // (uniform)
+            if (!last_c) request_kv(u, c + 1, buf ^ 1);
+            else if (more) {
+                request_kv(u + ustep, 0, buf ^ 1);
+                request_q(u + ustep);
+            }
+            if (has_tile) {
+                const char *Ks = smem + buf * BUF, *Vs = Ks + KVB;
+                const int nkt = !LONG ? 1 : (last_c ? nkt_last : 8);
+                auto scores = [&](int kt, const f32x16 &init) __attribute__((always_inline)) {
+                    f32x16 t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(krow0 + kt * 32 + r, hf))), qf[0], init);
+                    if (KS == 2)
+                        t = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(krow0 + kt * 32 + r, 2 + hf))), qf[KS - 1], t);
+                    if (last_c && kt == nkt_last - 1 && ragged) {  // wave-uniform; only the last tile of the last chunk can hold clamped rows past the sequence: they do not take part
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (acc_row(e, hf) >= last_rows) t[e] = -INFINITY;
+                    }
+                    return t;
+                };
+                if (!shifted) {  // exact-maximum fallback, online over the chunks: this chunk's maximum, then the running sums are rescaled
+                    float mc = -INFINITY;
+#pragma unroll 1
+                    for (int kt = 0; kt < nkt; ++kt) {
+                        const f32x16 t = scores(kt, zero);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) mc = fmaxf(mc, t[e]);
+                    }
+                    mc = fmaxf(mc, xhalf(mc));
+                    if (c > 0) {  // (NC == 1: mx = mc as in the round-4 kernel, nothing to rescale)
+                        const float m_new = fmaxf(mx, mc), alpha = __builtin_amdgcn_exp2f(mx - m_new);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            o[e] *= alpha;
+                            lsum[e] *= alpha;
+                        }
+                        mx = m_new;
+                    } else
+                        mx = mc;
+                }
+                // Shifted by the bound (the usual case): NO shift is applied at all.  |s_ij| <= m_i <= 60, so exp2(s_ij) lies in [2^-60, 2^60]: it
+                // fits fp32 and bf16 (8 exponent bits) as it is, the sums over the keys stay far below the fp32 range, and the common factor 2^m_i
+                // cancels in O / l exactly as a shift would.  The score MFMA then starts from the constant 0 (an inline operand) instead of a
+                // 16-register preset that hipcc copies into the accumulator in front of every tile (16 of the 60 vector instructions per tile
+                // pair that the counters showed).  Exact-maximum fallback: the preset form.
+                // (XL: the fallback subtracts the maximum with a vector instruction per score instead - a cold path, and the 16-register preset
+                // beside two accumulator tiles that live across the chunk loop does not fit 128 registers)
+                f32x16 negmx;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) negmx[e] = (shifted || XL) ? 0.0f : -mx;
+                const float sub = (XL && !shifted) ? mx : 0.0f;
+                const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // eight bf16 1.0
+                auto tile = [&](int kt, const f32x16 &t) __attribute__((always_inline)) {
+                    float p[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(XL && !shifted ? t[e] - sub : t[e]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        u32x4 pw = {pack2(p[8 * s2], p[8 * s2 + 1]), pack2(p[8 * s2 + 2], p[8 * s2 + 3]),
+                                    pack2(p[8 * s2 + 4], p[8 * s2 + 5]), pack2(p[8 * s2 + 6], p[8 * s2 + 7])};
+                        const char *vb = Vs + (krow0 + kt * 32 + 16 * s2) * ROWB + v_off;
+                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb));
+                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb + 8 * ROWB));
+                        typedef __attribute__((ext_vector_type(8))) short s16x8;
+                        const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        o = mfma32(__builtin_bit_cast(bf16x8, vv), as_bf16x8(pw), o);
+                        if (!ones_col) lsum = mfma32(as_bf16x8(ones_w), as_bf16x8(pw), lsum);  // every row = sum over this tile's keys, column = query
+                    }
+                };
+                if (shifted) {
+                    if (!LONG) tile(0, scores(0, zero));
+                    else if (!XL) {
+#pragma unroll 2
+                        for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, zero));  // (fully unrolled, hipcc hoists every fragment address and spills)
+                    } else {
+#pragma unroll LSL_ATTN_XL_UNROLL
+                        for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, zero));
+                    }
+                } else {
+#pragma unroll 1
+                    for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, XL ? zero : negmx));
+                }
+            }
+            wait_vmcnt<0>();  // the next stage's rows (and, behind the last chunk, the next unit's query tile): requested a whole stage ago
+            asm volatile("" ::: "memory");
+            if (!last_c || more) patch_ones(buf ^ 1);
+            buf ^= 1;
+        }
         if (more) read_q(qn);
         if (has_tile) {
+            float l = lsum[0];
+            if (ones_col) {  // row 24 of O^T: register 12 of the lanes with hf == 0; the other half gets it by one exchange
+                const float mine = o[12], other = xhalf(mine);
+                l = hf ? other : mine;
+                if (!hf) o[12] = 0.0f;  // the padding channel itself stays zero in z
+            }
+            const float inv_l = 1.0f / l;
             // O^T -> the query image, rows = queries: lane (query r, half hf) writes channels 8 q4 + 4 hf .. + 3 (8 bytes) into the 16-byte slot of
             // chunk q4; then row-wise, 16 bytes per lane
 #pragma unroll
@@ -577,22 +664,19 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
                 const u32x2 pk = {pack2(o[4 * q4] * inv_l, o[4 * q4 + 1] * inv_l), pack2(o[4 * q4 + 2] * inv_l, o[4 * q4 + 3] * inv_l)};
                 *reinterpret_cast<u32x2 *>(qimg + k_swz<HDP>(r, q4) + 8 * hf) = pk;
             }
-            int head0;
-            const size_t tok0 = unit_tok0(u, head0);
-            const char *zb = uni_ptr(reinterpret_cast<const char *>(a.z) + 2 * (tok0 * a.zw + (size_t)head0 * HDP));
+            const char *zb = uni_ptr(reinterpret_cast<const char *>(a.z) + 2 * ((tok0 + (size_t)(256 * qg) * a.pos_stride) * a.zw + (size_t)head0 * HDP));
 #pragma unroll
             for (int k = 0; k < OPW; ++k) {
                 const int R = RPI * k + lane / CPR;
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(qimg + k_swz<HDP>(R, lane % CPR));
                 const unsigned vz = voff_zr[k];
-                if (zr_ok[k]) {
+                if ((QIMG >= 1024 || lane < QIMG / 16) && (LONG ? 32 * wave : 0) + R < (LONG ? (last_g ? qrows_last : 256) : S)) {
                     if (a.nt) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(vz), "v"(v), "s"(zb) : "memory");
                     else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vz), "v"(v), "s"(zb) : "memory");
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image has been read before the next query tile is requested into it
         }
-        buf ^= 1;
     }
     wait_vmcnt<0>();
 }

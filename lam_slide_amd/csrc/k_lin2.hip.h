@@ -49,7 +49,7 @@ struct Lin2Args {
 };
 
 #ifndef LIN2_PROBE
-#define LIN2_PROBE 0  // tools/lin2_harness.hip only (results wrong): 1 no epilogue arithmetic + residual traffic, 2 no MFMAs, 4 no stores, 8 no token DMA, 32 no residual DMA, 128 cycle stamps, 256 every MFMA twice (a second accumulator on the same operands: what a 64-feature wave would issue per fragment)
+#define LIN2_PROBE 0  // tools/lin2_harness.hip only (results wrong): 1 no epilogue arithmetic + residual traffic, 2 no MFMAs, 4 no stores, 8 no token DMA, 32 no residual DMA, 128 cycle stamps, 256 every MFMA twice (a second accumulator on the same operands: what a 64-feature wave would issue per fragment), 512 every token-chunk request wraps inside a 4-block window of its range (all of them L2 hits: the ceiling of anything that turns the slices' shared misses into hits - leader rotation), 1024 the hi waves also store a bf16 row segment per token (64 B per row and wave: the `a` a fused LayerNorm would write) to Lin2Args::dbg
 #endif
 #ifndef LIN2_HI_FIRST
 #define LIN2_HI_FIRST 0  // 1: waves 0-3 (the older half, which wins the issue arbitration) finish the chains and run the epilogue
@@ -183,8 +183,9 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
     // source row 8 p of chunk (m, j), its per-lane offsets; past the last block-step the requests still go out, clamped: the counted waits
     // rely on 8 per chunk-step
     auto chunk_src = [&](int m, int j, unsigned &voff) __attribute__((always_inline)) {
-        const int mh = min(max(m - 1, 0), nblk - 1), ml = min(m, nblk - 1);
+        int mh = min(max(m - 1, 0), nblk - 1), ml = min(m, nblk - 1);
         voff = ml > mh ? voff_next : voff_same;
+        if (LIN2_PROBE & 512) mh &= 3;
         return reinterpret_cast<const char *>(g.Z) + ((size_t)(blk0 + mh) * 32 + 8 * p) * (2 * K) + (size_t)j * (2 * KC);
     };
 
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
                 if (B >= 1) {
                     if (!(LIN2_PROBE & 33)) {
                         if (!HB2) wait_vmcnt<0>();
-                        else if (B >= 2) wait_vmcnt<8>();
+                        else if (B >= 2) wait_vmcnt<8 + ((LIN2_PROBE & 1024) ? 2 : 0)>();
                         else wait_vmcnt<4>();
                     }
                     asm volatile("" ::: "memory");
@@ -443,6 +444,16 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
             if (J == 1 && B >= 1) {
 #pragma unroll
                 for (int k = IN_CHAIN; k < 4; ++k) epi_store(B - 1, k, false);
+                if (LIN2_PROBE & 1024) {  // (timing probe) 32 rows x 64 B of bf16 per wave and block: two 16-row instructions, 4 lanes per row
+                    const int l = opaque_lane();
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(hbuf + hb_off(B - 1) + k * 1024 + l * 16);
+                        const unsigned n = (unsigned)min((blk0 + B - 1) * 32 + 16 * k + (l >> 2), g.N - 1);
+                        const unsigned voff = n * (2u * g.F) + 2u * f0 + 16u * (l & 3);
+                        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(g.dbg) : "memory");
+                    }
+                }
             }
             slot = next_slot(slot);
         };

@@ -611,13 +611,14 @@ void launch_attention_rows(const AttnArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)((items + ITEMS - 1) / ITEMS)), dim3(NW * 64), lds, st, a);
 }
 
-// persistent, double-buffered form (k_attention_stream): axes of 129 .. 256 positions (one (sequence, head) per unit) and of 9 .. 32 positions
+// persistent, double-buffered form (k_attention_stream): axes of more than 128 positions (unit = (sequence, head, group of 256 queries), keys in
+// chunks of 256: peptide's T = 1000 is 4 groups x 4 chunks) and of 9 .. 32 positions
 // with a multiple of 8 heads (8 heads of a sequence per unit).  The choice depends on the model and on T, L only - never on the batch - so a
 // trajectory's bits are the same in any batch.  LSL_ATTN_STREAM=0 (read in the product too: A/B runs) keeps k_attention_rows.
 int attention_stream_mode(int S, int H) {  // 0: k_attention_rows / tiny / online, 1: stream SHORT, 2: stream LONG
     static const int on = env_int("LSL_ATTN_STREAM", 1);
     if (!on) return 0;
-    if (S > 128 && S <= 256) return 2;
+    if (S > 128) return 2;  // (round 5: any length - keys in chunks of 256 through the two images, queries in groups of 8 tiles)
     if (S > 8 && S <= 32 && H % 8 == 0) return 1;
     return 0;
 }
@@ -626,7 +627,7 @@ int attention_stream_mode(int S, int H) {  // 0: k_attention_rows / tiny / onlin
 bool qkv_planes_ok(int hdp, int hidden, int heads, int S, bool temporal, bool lin1_ts) {
     static const int on = env_int("LSL_QKV_PLANES", 1);
     (void)hidden;
-    return on && !temporal && lin1_ts && heads % (64 / hdp) == 0 && attention_stream_mode(S, heads) == 2;
+    return on && !temporal && lin1_ts && heads % (64 / hdp) == 0 && S <= 256 && attention_stream_mode(S, heads) == 2;
 }
 template <int HDP>
 bool launch_attention_stream(const AttnArgs &a, hipStream_t st) {
@@ -634,7 +635,7 @@ bool launch_attention_stream(const AttnArgs &a, hipStream_t st) {
     const bool is_long = mode == 2;
     if (!mode || !a.kmax2) return false;
     const size_t lds = (size_t)2 * 2 * 256 * HDP * 2 + (size_t)8 * 32 * HDP * 2;  // two images of K | V, 256 rows each; a 32-row query image per wave
-    const long n_units = is_long ? (long)a.n_seq * a.H : (long)a.n_seq * (a.H / 8);
+    const long n_units = is_long ? (long)a.n_seq * a.H * (((a.S + 31) / 32 + 7) / 8) : (long)a.n_seq * (a.H / 8);  // LONG: (sequence, head, group of 8 query tiles)
     const int grid = (int)std::min<long>(2L * device_cus(), n_units);  // two workgroups per CU (2 x 80 KiB of LDS at 32-wide heads)
     // plain stores: behind streaming stores the in-order vector-memory queue reports the next unit's requests late (measured: 0.78 vs 0.27 ms)
     AttnArgs b = a;
@@ -644,7 +645,11 @@ bool launch_attention_stream(const AttnArgs &a, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, b);
     };
     if (!is_long) go2(k_attention_stream<HDP, false>);
-    else go2(k_attention_stream<HDP, true>);
+    else if (a.S <= 256) go2(k_attention_stream<HDP, true>);
+    else if constexpr (HDP == 32) {  // keys in chunks of 256, queries in groups of 8 tiles
+        if (a.hd == 24) go2(k_attention_stream<HDP, true, true, true>);  // (peptide: the padded head's spare V column carries the softmax denominator)
+        else go2(k_attention_stream<HDP, true, true>);
+    } else go2(k_attention_stream<HDP, true, true>);
     return true;
 }
 

@@ -734,7 +734,8 @@ def test_general_path_rerun_bits(kw, B, T, L, dev):
 def test_attention_stream_kernel_against_rows_kernel(dev):
     """k_attention_stream (persistent, LDS-DMA double-buffered; the large axes of every config) against k_attention_rows (LSL_ATTN_STREAM=0)
     on the attention output of one spatial and one temporal sub-block: ragged last key tile (S = 200, 30, 9), both head widths, the
-    head-major q / k / v planes (hidden 512) and token-major rows, more and fewer units than workgroups.  The two differ only by the bf16
+    head-major q / k / v planes (hidden 512) and token-major rows, more and fewer units than workgroups; round 5: the chunked form for axes
+    beyond 256 positions (S = 1000 with 24-wide heads and the denominator column - peptide -, 300, 700, 512 = two full chunks).  The two differ only by the bf16
     rounding of the probabilities (another softmax shift): 1.6 - 2.2e-3 relative L2 measured."""
     import os
     import subprocess
@@ -749,7 +750,11 @@ def test_attention_stream_kernel_against_rows_kernel(dev):
         "for name, kw, B, T, L in (('d512', dict(depth=1, in_dim=16, hidden_size=512, num_heads=16, mlp_ratio=2), 2, 30, 200),\n"
         "                          ('d512_full', dict(depth=1, in_dim=16, hidden_size=512, num_heads=16, mlp_ratio=2), 40, 9, 256),\n"
         "                          ('d256', dict(depth=1, in_dim=16, hidden_size=256, num_heads=16, mlp_ratio=2), 3, 20, 192),\n"
-        "                          ('d128', dict(depth=1, in_dim=16, hidden_size=128, num_heads=8, mlp_ratio=2), 5, 32, 130)):\n"
+        "                          ('d128', dict(depth=1, in_dim=16, hidden_size=128, num_heads=8, mlp_ratio=2), 5, 32, 130),\n"
+        "                          ('pep_xl', dict(depth=1, in_dim=16, hidden_size=384, num_heads=16, mlp_ratio=4), 2, 1000, 2),\n"
+        "                          ('d512_xl', dict(depth=1, in_dim=16, hidden_size=512, num_heads=16, mlp_ratio=2), 1, 3, 300),\n"
+        "                          ('d256_xl', dict(depth=1, in_dim=16, hidden_size=256, num_heads=16, mlp_ratio=2), 1, 2, 700),\n"
+        "                          ('d128_xl512', dict(depth=1, in_dim=16, hidden_size=128, num_heads=8, mlp_ratio=2), 2, 512, 3)):\n"
         "    sh = latent_net.NetShape(**kw)\n"
         "    net = build_net(sh, latent_net.random_params(sh, seed=21), dev); net.ensure_packed(dev)\n"
         "    D = kw['hidden_size']; g = torch.Generator().manual_seed(3)\n"

@@ -51,10 +51,10 @@ prof|profile)
   one=(python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu --no-extras --no-roofline "$@")
   if [ "$cmd" = profile ]; then  # the driver's default step count in the trace, so its averages compare with bench.py's HIP-event figure
     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --no-cpu --no-extras --no-roofline "$@" > "$out/trace.log" 2>&1
-    pmc_pass "$out" pmc_sq "$SQ_WAIT" "${one[@]}"
   else
     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- "${one[@]}" > "$out/trace.log" 2>&1
   fi
+  pmc_pass "$out" pmc_sq "$SQ_WAIT" "${one[@]}"
   pmc_pass "$out" pmc_sq2 "$SQ_INST" "${one[@]}"
   pmc_pass "$out" pmc_tcc "$TCC" "${one[@]}"
   pmc_pass "$out" pmc_fetch FETCH_SIZE "${one[@]}"

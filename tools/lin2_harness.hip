@@ -88,8 +88,9 @@ void run_case(int N, int F, int tpt, int shared, int iters, int rpx_arg) {
     int gate_rows = shared ? 1 : (max_blocks * 32 + tpt - 1) / tpt + 1;
     if (gate_rows > C2::max_gate_rows) { printf("  gate table too large (%d rows > %d)\n", gate_rows, C2::max_gate_rows); return; }
     unsigned long long *dbg;
-    CK(hipMalloc(&dbg, 256 * 8 * 16 * 8));
-    CK(hipMemset(dbg, 0, 256 * 8 * 16 * 8));
+    const size_t dbg_bytes = (LIN2_PROBE & 1024) ? (size_t)N * F * 2 + 4096 : (size_t)256 * 8 * 16 * 8;  // (probe 1024: the bf16 rows a fused LayerNorm would write)
+    CK(hipMalloc(&dbg, dbg_bytes));
+    CK(hipMemset(dbg, 0, dbg_bytes));
     Lin2Args la{Wp, Z, b, gate, h1, F, N, mod_stride, tpt, magic_of(tpt), slices, rpx, gate_rows, dbg};
     auto knew = k_linear2_ws<K, LIN2_NCH, LIN2_NS, LIN2_HB2 != 0>;
     const size_t lds_new = C2::lds_bytes(gate_rows);
