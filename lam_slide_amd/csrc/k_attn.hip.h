@@ -30,6 +30,9 @@ struct AttnArgs {
     int bound;       // k_attention_rows: 1 = softmax shifted by the Cauchy-Schwarz bound |q| max|k| instead of the row maximum when that is safe
     int planes, npad;    // k_attention_stream (spatial): 1 = q / k / v are head-major planes qkv[section][head][npad tokens][HDP] (k_lin1.hip.h)
     const float *kmax2;  // k_attention_stream: device scalar, an upper bound of |k_j|^2 for every key of this block (head_dim max_d ks_d^2: k_rope_scaled)
+    int blk, n_tok;      // k_attention_stream SHORT, tiny spatial axes (round 5): blk > 0 = the launch presents 32 / blk consecutive sequences of blk
+                         // positions (a power of two <= 16) as ONE 32-row sequence (S = 32, n_seq = tiles of 32 tokens): scores outside the
+                         // block diagonal are masked; n_tok = valid tokens (rows of the last tile past it are not stored)
 };
 
 template <int HDP>
@@ -417,7 +420,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         const int item_local = LONG ? 0 : R >> 5;
         row_kv[k] = LONG ? R : R & 31;
         cst_kv[k] = planes ? 2u * ((unsigned)(1 + kv) * a.H * a.npad * HDP + chunk * 8) : 2u * ((1 + kv) * a.HHD + item_local * HDP + chunk * 8);
-        if (!XL) cst_kv[k] += pos_bytes * (unsigned)min(row_kv[k], S - 1);
+        if (!XL && !(!LONG && a.blk > 0)) cst_kv[k] += pos_bytes * (unsigned)min(row_kv[k], S - 1);  // (packed tiny axes: clamped per unit, below)
     }
 
     auto unit_tok0 = [&](long u, int &head0, int &qg) __attribute__((always_inline)) {
@@ -449,7 +452,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         const int R = RPI * k + lane / CPR, slot = lane % CPR;  // tile row, 16-byte slot
         const int chunk = slot ^ (HDP == 32 ? (R >> 2) & 3 : (R >> 3) & 1);
         cst_qt[k] = 2u * ((LONG ? 0 : wave * HDP) + chunk * 8);
-        if (!XL) cst_qt[k] += pos_bytes * (unsigned)min((LONG ? 32 * wave : 0) + R, S - 1);
+        if (!XL && !(!LONG && a.blk > 0)) cst_qt[k] += pos_bytes * (unsigned)min((LONG ? 32 * wave : 0) + R, S - 1);
     }
     // K | V rows of key chunk c of unit u -> image SET
     auto request_kv = [&](long u, int c, int SET) __attribute__((always_inline)) {
@@ -463,7 +466,10 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
             const int i = wave * IPW + k;
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + SET * BUF + (i / (NI / 2)) * KVB + (i % (NI / 2)) * 1024);
             // (!XL: one stage per unit, the clamped position was folded into cst_kv once)
-            const unsigned vk = XL ? cst_kv[k] + pos_bytes * (unsigned)min(row_kv[k], (last ? rows_last : 256) - 1) : cst_kv[k];
+            // packed tiny axes: the last tile of the launch may hold fewer than 32 tokens - rows past the end repeat the last one (finite values:
+            // their probabilities are exactly 0, but 0 x an uninitialised V row could still be NaN)
+            const unsigned vk = XL ? cst_kv[k] + pos_bytes * (unsigned)min(row_kv[k], (last ? rows_last : 256) - 1)
+                                   : ((!LONG && a.blk > 0) ? cst_kv[k] + pos_bytes * (unsigned)min(row_kv[k], min(32, a.n_tok - (int)tok0) - 1) : cst_kv[k]);
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vk), "s"(base), "s"(dst) : "memory");
         }
     };
@@ -478,7 +484,8 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         for (int k = 0; k < QPW; ++k) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + 2 * BUF + wave * QIMG + k * 1024);
             const int R = RPI * k + lane / CPR, lim = (LONG ? (last ? qrows_last : 256) : S) - 1;
-            const unsigned vq = XL ? cst_qt[k] + pos_bytes * (unsigned)max(min(32 * wave + R, lim), 0) : cst_qt[k];
+            const unsigned vq = XL ? cst_qt[k] + pos_bytes * (unsigned)max(min(32 * wave + R, lim), 0)
+                                   : ((!LONG && a.blk > 0) ? cst_qt[k] + pos_bytes * (unsigned)min(R, min(32, a.n_tok - (int)tok0) - 1) : cst_qt[k]);
             if (QIMG >= 1024 || lane < QIMG / 16)
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vq), "s"(base), "s"(dst) : "memory");
         }
@@ -501,6 +508,16 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) zero[e] = 0.0f;
     const float kmax2 = a.kmax2 ? *a.kmax2 : 0.0f;
+    // tiny axes packed 32 / blk sequences to a tile (AttnArgs::blk): bit e of the lane = accumulator register e holds a key of the lane's own
+    // sequence (key row acc_row(e, hf), query row r: same block of blk rows)
+    const bool grouped = !LONG && a.blk > 0;  // (uniform)
+    unsigned own_bits = 0xFFFFu;
+    if (grouped) {
+        own_bits = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (acc_row(e, hf) / a.blk == r / a.blk) own_bits |= 1u << e;
+    }
 
     // Output: a wave's tile O^T (32 queries on the lanes, HDP channels on the accumulator rows) goes through the wave's query image - free
     // once the NEXT unit's query tile has been read into registers - and leaves as whole row pieces, 16 bytes per lane (HDP = 32: 16 rows x
@@ -577,6 +594,11 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e)
                             if (acc_row(e, hf) >= last_rows) t[e] = -INFINITY;
+                    }
+                    if (!LONG && grouped) {  // (uniform) keys of the tile's other sequences do not take part
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (!((own_bits >> e) & 1u)) t[e] = -INFINITY;
                     }
                     return t;
                 };
@@ -670,7 +692,8 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
                 const int R = RPI * k + lane / CPR;
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(qimg + k_swz<HDP>(R, lane % CPR));
                 const unsigned vz = voff_zr[k];
-                if ((QIMG >= 1024 || lane < QIMG / 16) && (LONG ? 32 * wave : 0) + R < (LONG ? (last_g ? qrows_last : 256) : S)) {
+                if ((QIMG >= 1024 || lane < QIMG / 16) && (LONG ? 32 * wave : 0) + R < (LONG ? (last_g ? qrows_last : 256) : S) &&
+                    (!grouped || (long)tok0 + R < (long)a.n_tok)) {
                     if (a.nt) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(vz), "v"(v), "s"(zb) : "memory");
                     else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vz), "v"(v), "s"(zb) : "memory");
                 }

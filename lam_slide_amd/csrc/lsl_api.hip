@@ -629,8 +629,25 @@ bool qkv_planes_ok(int hdp, int hidden, int heads, int S, bool temporal, bool li
     (void)hidden;
     return on && !temporal && lin1_ts && heads % (64 / hdp) == 0 && S <= 256 && attention_stream_mode(S, heads) == 2;
 }
+// tiny SPATIAL axes (L = 2, 4, 8: positions and sequences are consecutive tokens) on the SHORT stream kernel, 32 / L sequences to a tile with
+// the scores outside the block diagonal masked (AttnArgs::blk): replaces k_attention_tiny.  LSL_ATTN_GROUP=0 keeps the lane-per-query kernel.
+bool attention_grouped_ok(const AttnArgs &a) {
+    static const int on = env_int("LSL_ATTN_GROUP", 1), stream_on = env_int("LSL_ATTN_STREAM", 1);
+    return on && stream_on && a.S >= 2 && a.S <= 8 && (a.S & (a.S - 1)) == 0 && a.inner == 1 && a.pos_stride == 1 && a.outer_stride == a.S && a.H % 8 == 0 &&
+           a.kmax2 != nullptr;
+}
 template <int HDP>
-bool launch_attention_stream(const AttnArgs &a, hipStream_t st) {
+bool launch_attention_stream(const AttnArgs &a_in, hipStream_t st) {
+    AttnArgs a = a_in;
+    a.blk = 0;
+    a.n_tok = 0;
+    if (attention_grouped_ok(a)) {  // present the tokens as sequences of 32 rows
+        a.blk = a.S;
+        a.n_tok = a.n_seq * a.S;
+        a.n_seq = (a.n_tok + 31) / 32;
+        a.S = 32;
+        a.outer_stride = 32;
+    }
     const int mode = attention_stream_mode(a.S, a.H);
     const bool is_long = mode == 2;
     if (!mode || !a.kmax2) return false;

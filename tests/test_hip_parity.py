@@ -735,7 +735,9 @@ def test_attention_stream_kernel_against_rows_kernel(dev):
     """k_attention_stream (persistent, LDS-DMA double-buffered; the large axes of every config) against k_attention_rows (LSL_ATTN_STREAM=0)
     on the attention output of one spatial and one temporal sub-block: ragged last key tile (S = 200, 30, 9), both head widths, the
     head-major q / k / v planes (hidden 512) and token-major rows, more and fewer units than workgroups; round 5: the chunked form for axes
-    beyond 256 positions (S = 1000 with 24-wide heads and the denominator column - peptide -, 300, 700, 512 = two full chunks).  The two differ only by the bf16
+    beyond 256 positions (S = 1000 with 24-wide heads and the denominator column - peptide -, 300, 700, 512 = two full chunks) and the tiny
+    spatial axes (L = 2, 4, 8) packed 32 / L sequences to a tile with a block-diagonal mask, against k_attention_tiny (fp32 probabilities),
+    a last tile of 12 tokens included.  The two differ only by the bf16
     rounding of the probabilities (another softmax shift): 1.6 - 2.2e-3 relative L2 measured."""
     import os
     import subprocess
@@ -754,7 +756,9 @@ def test_attention_stream_kernel_against_rows_kernel(dev):
         "                          ('pep_xl', dict(depth=1, in_dim=16, hidden_size=384, num_heads=16, mlp_ratio=4), 2, 1000, 2),\n"
         "                          ('d512_xl', dict(depth=1, in_dim=16, hidden_size=512, num_heads=16, mlp_ratio=2), 1, 3, 300),\n"
         "                          ('d256_xl', dict(depth=1, in_dim=16, hidden_size=256, num_heads=16, mlp_ratio=2), 1, 2, 700),\n"
-        "                          ('d128_xl512', dict(depth=1, in_dim=16, hidden_size=128, num_heads=8, mlp_ratio=2), 2, 512, 3)):\n"
+        "                          ('d128_xl512', dict(depth=1, in_dim=16, hidden_size=128, num_heads=8, mlp_ratio=2), 2, 512, 3),\n"
+        "                          ('nba_packed', dict(depth=1, in_dim=16, hidden_size=256, num_heads=16, mlp_ratio=4), 3, 20, 8),\n"
+        "                          ('l4_packed_ragged', dict(depth=1, in_dim=16, hidden_size=256, num_heads=8, mlp_ratio=2), 1, 11, 4)):\n"
         "    sh = latent_net.NetShape(**kw)\n"
         "    net = build_net(sh, latent_net.random_params(sh, seed=21), dev); net.ensure_packed(dev)\n"
         "    D = kw['hidden_size']; g = torch.Generator().manual_seed(3)\n"

@@ -44,18 +44,47 @@ def parse(path):
     return stats, counters
 
 
+def bench_line(path):
+    """The bench.py JSON line that tools/gpu.sh writes into the head of a summary ("# bench line of the traced run:")."""
+    for line in open(path):
+        if line.startswith("{") and '"metric"' in line:
+            try:
+                return json.loads(line)
+            except ValueError:
+                return None
+    return None
+
+
+def flops_per_step(cfg):
+    """F_fwd = 6 N C D + depth * 4 N D (4D + 2M + L + T) per trajectory and evaluation (bench.py: flops_per_eval_per_traj)."""
+    D, C, T, L = cfg["D"], cfg["C"], cfg["T"], cfg["L"]
+    M, n = int(D * cfg["mlp_ratio"]), T * L
+    return (6 * n * C * D + cfg["depth"] * 4 * n * D * (4 * D + 2 * M + L + T)) * cfg["state_updates"] * cfg["batch_per_gpu"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("summary")
-    ap.add_argument("--workload", default="md17_bench")
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--tokens-per-traj", type=int, default=30 * 256)
-    ap.add_argument("--calls", type=int, required=True, help="sampling calls in the kernel-trace run")
+    ap.add_argument("--workload", default=None, help="(default: from the bench line in the summary)")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--tokens-per-traj", type=int, default=0)
+    ap.add_argument("--calls", type=int, default=0, help="sampling calls in the kernel-trace run (default: steps + warmup of the bench line)")
     ap.add_argument("--updates", type=int, default=0, help="state updates per sampling call of the profiled command (bench.py --updates; 0 = not recorded)")
     ap.add_argument("--commit", default="", help="git commit of the library the profile was taken with (recorded; bench.py names it beside the derived figures)")
-    ap.add_argument("--flops-per-step", type=float, default=0.0, help="algorithmic FLOPs of one step (bench.py prints whole_path_tflops * s)")
+    ap.add_argument("--flops-per-step", type=float, default=0.0, help="algorithmic FLOPs of one step (default: SURVEY 8(d)'s formula on the bench line's config)")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
+    bl = bench_line(a.summary)
+    if bl:
+        cfg = bl["config"]
+        a.workload = a.workload or cfg["workload"]
+        a.batch = a.batch or cfg["batch_per_gpu"]
+        a.tokens_per_traj = a.tokens_per_traj or cfg["T"] * cfg["L"]
+        a.calls = a.calls or bl["steps"] + bl["warmup"]
+        a.updates = a.updates or cfg["state_updates"]
+        a.flops_per_step = a.flops_per_step or float(flops_per_step(cfg))
+    if not (a.workload and a.batch and a.tokens_per_traj and a.calls):
+        ap.error("no bench line in the summary: give --workload --batch --tokens-per-traj --calls")
     stats, counters = parse(a.summary)
     kernels = {}
     for name, st in stats.items():
