@@ -369,9 +369,10 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
 #ifndef LSL_ATTN_XL_UNROLL
 #define LSL_ATTN_XL_UNROLL 1
 #endif
-template <int HDP, bool LONG, bool XL = false, bool ONES = false>
+template <int HDP, bool LONG, bool XL = false, bool ONES = false, bool PACK = false>
 __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
     static_assert(LONG || !XL, "chunked keys / grouped queries exist for the LONG form only");
+    static_assert(!LONG || !PACK, "packed tiny axes run the SHORT form");
     static_assert(!ONES || (XL && HDP == 32), "the denominator column needs a padded head (head_dim 24 of 32); instantiated for the chunked form");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = HDP * 2, CPR = ROWB / 16, KS = HDP / 16;
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         const int item_local = LONG ? 0 : R >> 5;
         row_kv[k] = LONG ? R : R & 31;
         cst_kv[k] = planes ? 2u * ((unsigned)(1 + kv) * a.H * a.npad * HDP + chunk * 8) : 2u * ((1 + kv) * a.HHD + item_local * HDP + chunk * 8);
-        if (!XL && !(!LONG && a.blk > 0)) cst_kv[k] += pos_bytes * (unsigned)min(row_kv[k], S - 1);  // (packed tiny axes: clamped per unit, below)
+        if (!XL && !PACK) cst_kv[k] += pos_bytes * (unsigned)min(row_kv[k], S - 1);  // (packed tiny axes: clamped per unit, below)
     }
 
     auto unit_tok0 = [&](long u, int &head0, int &qg) __attribute__((always_inline)) {
@@ -452,7 +453,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         const int R = RPI * k + lane / CPR, slot = lane % CPR;  // tile row, 16-byte slot
         const int chunk = slot ^ (HDP == 32 ? (R >> 2) & 3 : (R >> 3) & 1);
         cst_qt[k] = 2u * ((LONG ? 0 : wave * HDP) + chunk * 8);
-        if (!XL && !(!LONG && a.blk > 0)) cst_qt[k] += pos_bytes * (unsigned)min((LONG ? 32 * wave : 0) + R, S - 1);
+        if (!XL && !PACK) cst_qt[k] += pos_bytes * (unsigned)min((LONG ? 32 * wave : 0) + R, S - 1);
     }
     // K | V rows of key chunk c of unit u -> image SET
     auto request_kv = [&](long u, int c, int SET) __attribute__((always_inline)) {
@@ -469,7 +470,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
             // packed tiny axes: the last tile of the launch may hold fewer than 32 tokens - rows past the end repeat the last one (finite values:
             // their probabilities are exactly 0, but 0 x an uninitialised V row could still be NaN)
             const unsigned vk = XL ? cst_kv[k] + pos_bytes * (unsigned)min(row_kv[k], (last ? rows_last : 256) - 1)
-                                   : ((!LONG && a.blk > 0) ? cst_kv[k] + pos_bytes * (unsigned)min(row_kv[k], min(32, a.n_tok - (int)tok0) - 1) : cst_kv[k]);
+                                   : (PACK ? cst_kv[k] + pos_bytes * (unsigned)min(row_kv[k], min(32, a.n_tok - (int)tok0) - 1) : cst_kv[k]);
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vk), "s"(base), "s"(dst) : "memory");
         }
     };
@@ -485,7 +486,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + 2 * BUF + wave * QIMG + k * 1024);
             const int R = RPI * k + lane / CPR, lim = (LONG ? (last ? qrows_last : 256) : S) - 1;
             const unsigned vq = XL ? cst_qt[k] + pos_bytes * (unsigned)max(min(32 * wave + R, lim), 0)
-                                   : ((!LONG && a.blk > 0) ? cst_qt[k] + pos_bytes * (unsigned)min(R, min(32, a.n_tok - (int)tok0) - 1) : cst_qt[k]);
+                                   : (PACK ? cst_qt[k] + pos_bytes * (unsigned)min(R, min(32, a.n_tok - (int)tok0) - 1) : cst_qt[k]);
             if (QIMG >= 1024 || lane < QIMG / 16)
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vq), "s"(base), "s"(dst) : "memory");
         }
@@ -510,7 +511,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
     const float kmax2 = a.kmax2 ? *a.kmax2 : 0.0f;
     // tiny axes packed 32 / blk sequences to a tile (AttnArgs::blk): bit e of the lane = accumulator register e holds a key of the lane's own
     // sequence (key row acc_row(e, hf), query row r: same block of blk rows)
-    const bool grouped = !LONG && a.blk > 0;  // (uniform)
+    constexpr bool grouped = PACK;  // (the host selects the instance: AttnArgs::blk > 0)
     unsigned own_bits = 0xFFFFu;
     if (grouped) {
         own_bits = 0;
@@ -553,25 +554,8 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         const bool last_g = qg == QG - 1;                                     // (uniform)
         const bool has_tile = !LONG || 256 * qg + 32 * wave < S;              // (uniform) LONG: wave w = query tile w of the group
         const bool more = u + ustep < u1;                                     // (uniform)
-        // softmax bound of this wave's queries (see above): decided once per unit
         float mx = -INFINITY;
         bool shifted = false;
-        if (has_tile && a.kmax2) {
-            float qq = 0.0f;
-#pragma unroll
-            for (int s2 = 0; s2 < KS; ++s2) {
-                const u32x4 w = __builtin_bit_cast(u32x4, qf[s2]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
-                    qq = fmaf(lo, lo, fmaf(hi, hi, qq));
-                }
-            }
-            qq += xhalf(qq);
-            const float m = sqrtf(qq * kmax2) * 1.02f;
-            shifted = __ballot(m > 60.0f) == 0;  // (wave-uniform)
-            if (shifted) mx = m;
-        }
         f32x16 o = zero, lsum = zero;
 #pragma unroll 1
         for (int c = 0; c < NC; ++c) {  // stage (u, c)
@@ -582,6 +566,23 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
             else if (more) {
                 request_kv(u + ustep, 0, buf ^ 1);
                 request_q(u + ustep);
+            }
+            // softmax bound of this wave's queries (see above): decided once per unit, behind the barrier and the next stage's requests
+            if (c == 0 && has_tile && a.kmax2) {
+                float qq = 0.0f;
+#pragma unroll
+                for (int s2 = 0; s2 < KS; ++s2) {
+                    const u32x4 w = __builtin_bit_cast(u32x4, qf[s2]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+                        qq = fmaf(lo, lo, fmaf(hi, hi, qq));
+                    }
+                }
+                qq += xhalf(qq);
+                const float m = sqrtf(qq * kmax2) * 1.02f;
+                shifted = __ballot(m > 60.0f) == 0;  // (wave-uniform)
+                if (shifted) mx = m;
             }
             if (has_tile) {
                 const char *Ks = smem + buf * BUF, *Vs = Ks + KVB;
@@ -595,7 +596,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
                         for (int e = 0; e < 16; ++e)
                             if (acc_row(e, hf) >= last_rows) t[e] = -INFINITY;
                     }
-                    if (!LONG && grouped) {  // (uniform) keys of the tile's other sequences do not take part
+                    if (grouped) {  // keys of the tile's other sequences do not take part
 #pragma unroll
                         for (int e = 0; e < 16; ++e)
                             if (!((own_bits >> e) & 1u)) t[e] = -INFINITY;

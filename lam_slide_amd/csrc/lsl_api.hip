@@ -661,7 +661,8 @@ bool launch_attention_stream(const AttnArgs &a_in, hipStream_t st) {
         LSL_ALLOW_LDS(kern, lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, b);
     };
-    if (!is_long) go2(k_attention_stream<HDP, false>);
+    if (!is_long && a.blk > 0) go2(k_attention_stream<HDP, false, false, false, true>);
+    else if (!is_long) go2(k_attention_stream<HDP, false>);
     else if (a.S <= 256) go2(k_attention_stream<HDP, true>);
     else if constexpr (HDP == 32) {  // keys in chunks of 256, queries in groups of 8 tiles
         if (a.hd == 24) go2(k_attention_stream<HDP, true, true, true>);  // (peptide: the padded head's spare V column carries the softmax denominator)
