@@ -531,24 +531,6 @@ def run_rank(args) -> int:
                              "decode_ms": timed_call(lambda: dec.decode(flat, ent), reps=3) * 1e3,
                              "what": "device encode / decode of one step's batch (seeded frozen stage-1 weights), outside the timed region"}
 
-        # the opt-in two-lane mode (LSL_LANES=2: the two halves of the batch on two HIP streams, one half's memory-bound kernels under the
-        # other's GEMMs).  Not the headline: with overlapping kernels a kernel trace no longer shows per-kernel durations that
-        # can be set against a roofline, so `value` / `roofline` above are the single-stream run that profiles/ documents.  Measured here in
-        # a child process (the library reads the variable once), same workload, same batch.
-        if B * T * L >= 131072 and os.environ.get("LSL_LANES", "1") in ("", "0", "1") and not stub:
-            try:
-                import subprocess
-                env = dict(os.environ, LSL_LANES="2")
-                cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--batch", str(B), "--steps", "5", "--warmup", "2",
-                       "--no-cpu", "--no-extras"]
-                res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-                line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-                d2 = json.loads(line)
-                out["two_lanes"] = {"value": d2["value"], "unit": d2["unit"], "ms_per_step": d2["ms_per_step"], "vs_single_stream": d2["value"] / value,
-                                    "how": "child process with LSL_LANES=2, 5 timed steps after 2 warm-ups; opt-in mode, bit-identical results"}
-            except Exception as e:  # (a report-only leg: never fails the run)
-                out["two_lanes"] = {"error": repr(e)[:200]}
-
     if not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_leg(args, kw, T, L, method, skw, n_evals, init, mk, net, tr, dev)
         if out["cpu_baseline"]:

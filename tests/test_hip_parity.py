@@ -671,10 +671,10 @@ def test_graph_replay_matches_eager_bits(dev):
 
 def test_kernel_choice_knobs_do_not_change_bits(dev):
     """The knobs that pick between bit-identical kernel paths, exercised at the headline shape (T = 30, L = 256, D = 512: linear2 on the
-    weight-stationary kernel k_linear2_ws, 18 trajectories = 138 240 tokens so that LSL_LANES=2 really splits the batch over two
-    streams): LSL_LIN2_WS=0 (linear2 back on the 256 x 256-tile kernel), LSL_LANES=2 and the modulation tables computed per evaluation
-    (LSL_MODS_GROUP=0) or in groups of two records (=2: the default computes all records of the call in one group) must reproduce the
-    default run's bits.  The knobs are read once per process, so every arm runs in a subprocess."""
+    weight-stationary kernel k_linear2_ws, 18 trajectories = 138 240 tokens): LSL_LIN2_WS=0 (linear2 back on the 256 x 256-tile kernel),
+    LSL_QKV_PLANES=0 (q / k / v as token-major rows) and the modulation tables computed per evaluation (LSL_MODS_GROUP=0) or in groups of
+    two records (=2: the default computes all records of the call in one group) must reproduce the default run's bits.  The knobs are read
+    once per process, so every arm runs in a subprocess."""
     import os
     import subprocess
     import sys
@@ -692,18 +692,18 @@ def test_kernel_choice_knobs_do_not_change_bits(dev):
         "torch.save(drv.sample_latents(lat, init=init).cpu(), sys.argv[1])\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    arms = (("default", {}), ("tile_linear2", {"LSL_LIN2_WS": "0"}), ("two_lanes", {"LSL_LANES": "2"}), ("mods_per_eval", {"LSL_MODS_GROUP": "0"}),
-            ("mods_groups_of_2", {"LSL_MODS_GROUP": "2", "LSL_LANES": "2"}))
+    arms = (("default", {}), ("tile_linear2", {"LSL_LIN2_WS": "0"}), ("token_major_qkv", {"LSL_QKV_PLANES": "0"}), ("mods_per_eval", {"LSL_MODS_GROUP": "0"}),
+            ("mods_groups_of_2", {"LSL_MODS_GROUP": "2"}))
     for name, extra in arms:
         path = f"/tmp/lsl_knob_{name}_{os.getpid()}.pt"
-        env = {k: v for k, v in os.environ.items() if k not in ("LSL_LIN2_WS", "LSL_LANES", "LSL_MODS_GROUP")}
+        env = {k: v for k, v in os.environ.items() if k not in ("LSL_LIN2_WS", "LSL_QKV_PLANES", "LSL_MODS_GROUP")}
         env.update(extra)
         subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=900)
         res[name] = torch.load(path)
         os.remove(path)
     assert torch.isfinite(res["default"]).all()
     assert torch.equal(res["default"], res["tile_linear2"])
-    assert torch.equal(res["default"], res["two_lanes"])
+    assert torch.equal(res["default"], res["token_major_qkv"])
     assert torch.equal(res["default"], res["mods_per_eval"])
     assert torch.equal(res["default"], res["mods_groups_of_2"])
 
