@@ -411,19 +411,24 @@ def run_rank(args) -> int:
     def committed_traffic(key):
         """HBM-side bytes per launch of kernel `key` from the newest committed PMC profile of this workload, scaled to this run's
         tokens per launch; not measured in this run (PMC counters need rocprofv3): the source file is named beside the number."""
-        for tf in traffic_files():
-            try:
-                tj = json.load(open(tf))
-                if key and tj["workload"] == args.workload and key in tj:
-                    return int(tj[key]["bytes"] / tj["tokens_per_launch"] * min(pass_size, B) * T * L), os.path.relpath(tf, ROOT)
-            except (OSError, KeyError, ValueError):
-                continue
+        for tf, tj in traffic_files():
+            if key and key in tj:
+                return int(tj[key]["bytes"] / tj["tokens_per_launch"] * min(pass_size, B) * T * L), os.path.relpath(tf, ROOT)
         return None, None
 
     def traffic_files():
-        """committed PMC-derived traffic files, newest round first: profiles/rNN_traffic.json (headline workload) and
-        profiles/rNN_traffic_<workload>.json"""
-        return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), key=lambda f: os.path.basename(f)[:3], reverse=True)
+        """(path, content) of the committed PMC-derived traffic files of THIS workload - profiles/rNN_traffic.json (headline) and
+        profiles/rNN_traffic_<workload>[_bNN].json -, newest round first, within a round the file profiled at this run's batch first."""
+        found = []
+        for tf in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")):
+            try:
+                tj = json.load(open(tf))
+            except (OSError, ValueError):
+                continue
+            if tj.get("workload") == args.workload and "tokens_per_launch" in tj:
+                found.append((os.path.basename(tf)[:3], tj.get("batch") == B, tf, tj))
+        found.sort(key=lambda e: (e[0], e[1]), reverse=True)
+        return [(tf, tj) for _, _, tf, tj in found]
 
     how = "separate sampling call after the timed region, per-launch HIP events on the launch stream (one stream, nothing co-running)"
     traffic, traffic_src = committed_traffic({0: "linear1", 1: "linear2"}.get(args.profile_kernel))
@@ -444,10 +449,9 @@ def run_rank(args) -> int:
     # committed rocprofv3 PMC passes, derived by tools/traffic_from_pmc.py), which scales with the tokens of a step (weights are < 1 %), so
     # the per-token figure is scaled to this run's batch; time = this run's measured step.  As the step is cut into kernels, its HBM floor
     # is ABOVE its MFMA floor: the decomposition, not any single kernel, is HBM-bound.
-    for tf in traffic_files():
+    for tf, tj in traffic_files():
         try:
-            tj = json.load(open(tf))
-            if tj.get("workload") != args.workload or "step" not in tj:
+            if "step" not in tj:
                 continue
             # bytes per token and state update (the profile may have been taken with fewer updates per call: --updates), scaled to this run
             per_tok_upd = tj["step"]["bytes_per_token"] / tj.get("state_updates", n_evals)

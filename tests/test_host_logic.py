@@ -527,26 +527,28 @@ def test_sample_ode_reverse_asserts_like_the_reference():
 
 
 def test_committed_traffic_file_reproduces_from_the_committed_pmc_summary(tmp_path):
-    """bench.py's `roofline_step` / `traffic` figures come from profiles/r*_traffic.json; that file must be what tools/traffic_from_pmc.py
-    derives from the committed rocprofv3 summary of the same round (no hand-edited numbers)."""
+    """bench.py's `roofline_step` / `traffic` figures come from profiles/rNN_traffic*.json; every such file of the newest round must be what
+    tools/traffic_from_pmc.py derives from the committed rocprofv3 summary it names (no hand-edited numbers), and every BASELINE
+    configuration family that runs the general kernels has one."""
     import glob
     import json
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    newest = [f for f in files if "step" in json.load(open(f))]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")))
+    newest_round = max(os.path.basename(f)[:3] for f in files)
+    newest = [f for f in files if os.path.basename(f).startswith(newest_round) and "step" in json.load(open(f))]
     assert newest, "no scripted traffic file committed"
-    committed = json.load(open(newest[-1]))
-    tag = os.path.basename(newest[-1]).split("_")[0]
-    summary = os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.txt")
-    out = tmp_path / "t.json"
-    calls = {v["trace_calls"] // v["launches_per_step"] for k, v in committed["kernels"].items() if k.startswith("k_") and v["launches_per_step"] >= 50}
-    assert len(calls) == 1
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_from_pmc.py"), summary, "--workload", committed["workload"], "--batch",
-                    str(committed["batch"]), "--calls", str(calls.pop()), "--flops-per-step",
-                    str(committed["step"]["mfma_floor_ms_at_2_5_pflop_s"] * 1e-3 * 2.5e15), "-o", str(out)], check=True, capture_output=True)
-    again = json.load(open(out))
-    assert again["step"]["bytes"] == committed["step"]["bytes"]
-    assert abs(again["step"]["kernel_ms"] - committed["step"]["kernel_ms"]) < 1e-6
-    for cls in ("linear1", "linear2", "attention", "ln_modulate"):
-        assert again[cls]["bytes"] == committed[cls]["bytes"] and again[cls]["kernel"] == committed[cls]["kernel"]
-    # the decomposition's floors as DESIGN.md section 5 states them: HBM floor above the MFMA floor
-    assert committed["step"]["hbm_floor_ms_at_8_tb_s"] > committed["step"]["mfma_floor_ms_at_2_5_pflop_s"]
+    workloads = set()
+    for f in newest:
+        committed = json.load(open(f))
+        workloads.add(committed["workload"])
+        summary = os.path.join(ROOT, committed["source"])
+        assert os.path.exists(summary), (f, committed["source"])
+        out = tmp_path / "t.json"
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_from_pmc.py"), summary, "--commit", committed.get("commit", ""), "-o", str(out)],
+                       check=True, capture_output=True, cwd=ROOT)
+        again = json.load(open(out))
+        assert again == committed, f
+        # the decomposition's floors as DESIGN.md section 5 states them: HBM floor above the MFMA floor
+        assert committed["step"]["hbm_floor_ms_at_8_tb_s"] > committed["step"]["mfma_floor_ms_at_2_5_pflop_s"] > 0, f
+        for cls in ("linear1", "linear2", "attention", "ln_modulate"):
+            assert committed[cls]["bytes"] > 0 and committed[cls]["avg_us"] > 0, (f, cls)
+    assert {"md17_bench", "md17_ref", "nba", "peptide"} <= workloads
