@@ -31,7 +31,9 @@ extern "C" {
 #endif
 
 /* 2: lsl_sample_ex takes n_trace; linear1 biases are read in whole 256-feature tiles (b1 zero-padded to a multiple of 256 floats);
- *    lsl_sample_ex, lsl_debug_taps, lsl_build_info exist. */
+ *    lsl_sample_ex, lsl_debug_taps, lsl_build_info exist.
+ * 3: lsl_rk_lincomb / lsl_rk_dense / lsl_rk_error_ratio exist (state arithmetic of the adaptive and fixed-grid Runge-Kutta samplers);
+ *    no signature of version 2 changed. */
 #define LSL_VERSION 3
 
 typedef struct lsl_model lsl_model;

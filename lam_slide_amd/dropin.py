@@ -9,9 +9,9 @@ re-exports) to :class:`lam_slide_amd.Sampler`, whose fused loop recognises a ``l
 sampler.  It is idempotent, touches only modules that are ALREADY imported (it never imports the reference itself), and is called
 automatically when a ``lam_slide_amd.LatentSIV3`` or ``lam_slide_amd.CreateTransport`` is constructed, i.e. precisely when one of the
 shipped overrides is active.  ``LSL_NO_INSTALL=1`` disables the automatic call; ``uninstall()`` restores the original names.
-What this package does not implement (torchdiffeq's adaptive ODE solvers: the reference's default ``dopri5``) is delegated to the class
-that was replaced (:func:`original_sampler`) when the call carries the reference's own ``Transport`` object, so other models of the
-same process keep working after the install.
+What this package does not implement (torchdiffeq solvers other than ``euler`` / ``midpoint`` / ``heun3`` / ``rk4`` and the reference's
+default ``dopri5``, which are native) is delegated to the class that was replaced (:func:`original_sampler`) when the call carries the
+reference's own ``Transport`` object, so other models of the same process keep working after the install.
 """
 from __future__ import annotations
 
