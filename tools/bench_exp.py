@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """bench.py against the -DLSL_EXPERIMENTS build (tools/build_experiments.sh): the only way the LSL_GEMM / LSL_PROBE / LSL_NT / ...
-knobs used by the tools/gpu_*.sh scripts take effect.  The library path is switched in this process only."""
+knobs (`EXP=1 tools/gpu.sh ab ...`) take effect.  The library path is switched in this process only."""
 import os
 import sys
 
