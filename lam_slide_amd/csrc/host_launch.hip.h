@@ -307,6 +307,13 @@ int gemm_variant(int F, int K, int N = 1 << 30) {
     const bool ragged = F % 256 != 0 && (F % 256 <= 128);
     const int ragged_variant = std::is_same<Epi, EpiLinear2>::value && K % 64 == 0 ? 11 : 10;  // measured on the D = 384 / 128 models
     if (forced >= 0) return forced;
+    // linear2 of the 384-wide models (peptide: F = 384, K = 2 048, which no weight-stationary instance holds): the launch is bound by the
+    // operand bytes each CU pulls through its L1 miss path (measured 49 GB/s per CU with two 128 x 128 workgroups per CU: the per-CU limit);
+    // 192 x 128 tiles move 17 % fewer operand bytes per FLOP with as many workgroups as CUs, and a third ring slot covers the latency one
+    // workgroup per CU leaves exposed: 63.5 -> 54.3 ms per 100 evaluations at 16 000 tokens (profiles/r05_experiments.txt).  Same bits as
+    // every other tiling (same k order per element).  Only when the tiles fill at least half of the CUs.
+    if (std::is_same<Epi, EpiLinear2>::value && F % 192 == 0 && F % 256 != 0 && K % 64 == 0 && (long)((N + 127) / 128) * (F / 192) * 2 >= (long)device_cus())
+        return 28;
     if (ragged) return ragged_variant;
     // Small launches (one or two trajectories of the MD17 models, the reference's own B = 4 case): 256 x 256 tiles leave most of the chip
     // idle or run two rounds for 1.2 rounds of work; 128 x 128 tiles (two workgroups per CU) fill it.  Measured (profiles/
@@ -363,7 +370,12 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
         case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
         case 10: return launch_gemm_glds<128, 128, 2, 2, 32, 3, false>(g, epi, st);
         case 11: return launch_gemm_glds<128, 128, 2, 2, 64, 2, false>(g, epi, st);
+        case 28:  // 192 features x 128 tokens, 8 waves of 96 x 32, three 64-deep ring slots (linear2 of the 384-wide models)
+            if constexpr (std::is_same<Epi, EpiLinear2>::value) return launch_gemm_glds<192, 128, 2, 4, 64, 3, false>(g, epi, st);
+            else break;
 #ifdef LSL_EXPERIMENTS
+        case 26: if constexpr (std::is_same<Epi, EpiLinear2>::value) return launch_gemm_glds<192, 128, 2, 4, 64, 2, false>(g, epi, st); else break;  // 192 features x 128 tokens, 8 waves of 96 x 32 (F = 384: 2 x 125 tiles at 16 000 tokens)
+        case 29: if constexpr (std::is_same<Epi, EpiLinear2>::value) return launch_gemm_glds<192, 256, 2, 4, 64, 2, false>(g, epi, st); else break;  // 8 waves of 96 x 64: 2 x 63 tiles
         case 23: return launch_gemm_glds<512, 128, 4, 2, 32, 3, false>(g, epi, st);  // whole residual rows per workgroup (F = 512): 120 KiB ring
         case 24: return launch_gemm_glds<512, 128, 4, 2, 32, 2, false>(g, epi, st);
         case 25: return launch_gemm_glds<512, 128, 4, 2, 32, 3, true>(g, EpiPieces<Epi>(epi), st);

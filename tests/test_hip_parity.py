@@ -712,7 +712,8 @@ def test_kernel_choice_knobs_do_not_change_bits(dev):
     (dict(depth=2, in_dim=32, hidden_size=512, num_heads=16, mlp_ratio=2), 20, 30, 256),   # headline model: k_linear2_ws<1536>, stream attention LONG (planes) + SHORT
     (dict(depth=2, in_dim=32, hidden_size=256, num_heads=16, mlp_ratio=4), 300, 20, 8),    # NBA family: k_linear2_ws<1280> (5 chunks), SHORT with 16-wide heads
     (dict(depth=2, in_dim=32, hidden_size=256, num_heads=16, mlp_ratio=2), 9, 30, 192),    # MD17 reference shape: k_linear2_ws<768>, LONG with 16-wide heads
-], ids=["md17", "nba", "md17_ref"])
+    (dict(depth=2, in_dim=32, hidden_size=384, num_heads=16, mlp_ratio=4), 3, 1000, 2),    # peptide family: chunked LONG (4 x 4 stages, denominator column), packed L = 2, tile linear2
+], ids=["md17", "nba", "md17_ref", "peptide"])
 def test_general_path_rerun_bits(kw, B, T, L, dev):
     """The round-4 kernels keep hand-counted vector-memory waits (LDS-DMA rings, hand-offs between waves through LDS): the same sampling
     call repeated 25 times must give the same bits every time (a miscounted wait shows as a timing-dependent difference, as the resident

@@ -32,8 +32,8 @@ def main():
         C = rng.choice([8, 16, 32, 32, 32, 48])
         vec = rng.choice([0, 0, 0, 6])
         depth = rng.choice([1, 2])
-        T = rng.choice([1, 2, 5, 9, 20, 30, 33, 64])
-        L = rng.choice([1, 2, 8, 21, 40, 130, 192, 256])
+        T = rng.choice([1, 2, 4, 5, 9, 20, 30, 33, 64, 300, 700])
+        L = rng.choice([1, 2, 4, 8, 21, 40, 130, 192, 256, 320])
         B = rng.choice([1, 2, 3, 5, 7])
         while B * T * L > 40000:
             B = max(1, B - 1)
