@@ -39,11 +39,11 @@ static u16 f2bf_host(float f) {
     return (u16)(u >> 16);
 }
 
-template <int K, int LIN2_NCH, int LIN2_NS>
+template <int K, int NCH_, int NS_>
 void run_case(int N, int F, int tpt, int shared, int iters, int rpx_arg) {
     const int Npad = (N + 255) / 256 * 256, Fpad = (F + 255) / 256 * 256;
     const int ntraj = (N + tpt - 1) / tpt, MODW = 6 * F + 64, mod_stride = shared ? 0 : MODW;
-    printf("case N=%d F=%d K=%d tokens/traj=%d shared_gate=%d  (chunks per block %d, ring slots %d, residual images %d)\n", N, F, K, tpt, shared, LIN2_NCH, LIN2_NS, LIN2_HB2 ? 2 : 1);
+    printf("case N=%d F=%d K=%d tokens/traj=%d shared_gate=%d  (chunks per block %d, ring slots %d, residual images %d)\n", N, F, K, tpt, shared, NCH_, NS_, LIN2_HB2 ? 2 : 1);
     std::vector<u16> hW((size_t)Fpad * K), hZ((size_t)Npad * K);
     std::vector<float> hb(Fpad), hg((size_t)ntraj * MODW), hh((size_t)N * F);
     for (auto &v : hW) v = f2bf_host(rndf() * 0.05f);
@@ -75,7 +75,7 @@ void run_case(int N, int F, int tpt, int shared, int iters, int rpx_arg) {
     const int tiles = ((N + 255) / 256) * (Fpad / 256);
     const int grid_old = tiles < 256 ? tiles : 256;
     // ---- new kernel ----
-    using C2 = Lin2Cfg<K, LIN2_NCH, LIN2_NS, LIN2_HB2 != 0>;
+    using C2 = Lin2Cfg<K, NCH_, NS_, LIN2_HB2 != 0>;
     hipLaunchKernelGGL(k_lin2_pack, dim3(256), dim3(256), 0, 0, Wp, W, F, K);
     CK(hipDeviceSynchronize());
     const int slices = F / 128;
@@ -92,7 +92,7 @@ void run_case(int N, int F, int tpt, int shared, int iters, int rpx_arg) {
     CK(hipMalloc(&dbg, dbg_bytes));
     CK(hipMemset(dbg, 0, dbg_bytes));
     Lin2Args la{Wp, Z, b, gate, h1, F, N, mod_stride, tpt, magic_of(tpt), slices, rpx, gate_rows, dbg};
-    auto knew = k_linear2_ws<K, LIN2_NCH, LIN2_NS, LIN2_HB2 != 0>;
+    auto knew = k_linear2_ws<K, NCH_, NS_, LIN2_HB2 != 0>;
     const size_t lds_new = C2::lds_bytes(gate_rows);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(knew), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     const int gnew = 8 * slices * rpx;
@@ -160,15 +160,16 @@ int main(int argc, char **argv) {
     const int tpt = argc > 4 ? atoi(argv[4]) : 7680, shared = argc > 5 ? atoi(argv[5]) : 1, iters = argc > 6 ? atoi(argv[6]) : 20;
     const int rpx = argc > 7 ? atoi(argv[7]) : 0;
 #ifndef LIN2_NCH
-    if (K == 1536) run_case<1536, 3, 3>(N, F, tpt, shared, iters, rpx);
-    else if (K == 768) run_case<768, 3, 3>(N, F, tpt, shared, iters, rpx);
-    else if (K == 1280) run_case<1280, 5, 5>(N, F, tpt, shared, iters, rpx);
-    else if (K == 384) run_case<384, 3, 3>(N, F, tpt, shared, iters, rpx);
-#else
-    if (K == 1536) run_case<1536, LIN2_NCH, LIN2_NS>(N, F, tpt, shared, iters, rpx);
-    else if (K == 1280) run_case<1280, LIN2_NCH, LIN2_NS>(N, F, tpt, shared, iters, rpx);
-    else if (K == 768) run_case<768, LIN2_NCH, LIN2_NS>(N, F, tpt, shared, iters, rpx);
+#define LIN2_NCH 0
+#define LIN2_NS 0
 #endif
+#ifndef LIN2_FOR_K
+#define LIN2_FOR_K 1536  // the width the LIN2_NCH / LIN2_NS override applies to; the others run their product instances
+#endif
+    if (K == 1536) run_case<1536, (LIN2_NCH && LIN2_FOR_K == 1536) ? LIN2_NCH : 3, (LIN2_NCH && LIN2_FOR_K == 1536) ? LIN2_NS : 3>(N, F, tpt, shared, iters, rpx);
+    else if (K == 768) run_case<768, (LIN2_NCH && LIN2_FOR_K == 768) ? LIN2_NCH : 3, (LIN2_NCH && LIN2_FOR_K == 768) ? LIN2_NS : 3>(N, F, tpt, shared, iters, rpx);
+    else if (K == 1280) run_case<1280, (LIN2_NCH && LIN2_FOR_K == 1280) ? LIN2_NCH : 4, (LIN2_NCH && LIN2_FOR_K == 1280) ? LIN2_NS : 4>(N, F, tpt, shared, iters, rpx);
+    else if (K == 384) run_case<384, 3, 3>(N, F, tpt, shared, iters, rpx);
     else printf("unsupported shape\n");
     return 0;
 }
