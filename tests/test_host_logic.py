@@ -552,3 +552,23 @@ def test_committed_traffic_file_reproduces_from_the_committed_pmc_summary(tmp_pa
         for cls in ("linear1", "linear2", "attention", "ln_modulate"):
             assert committed[cls]["bytes"] > 0 and committed[cls]["avg_us"] > 0, (f, cls)
     assert {"md17_bench", "md17_ref", "nba", "peptide"} <= workloads
+
+
+def test_runtime_switches_are_exactly_the_documented_ones():
+    """Every environment variable the product reads (library sources outside -DLSL_EXPERIMENTS tuning: env_int / getenv; the Python package:
+    os.environ) is a row of INTEGRATION.md section 6, and the table lists nothing that is not read - the list of switches cannot grow
+    unnoticed.  tools/gpu.sh, the one script of the GPU box, parses."""
+    import glob
+    import re
+    src = ""
+    for f in glob.glob(os.path.join(ROOT, "lam_slide_amd", "csrc", "*")):
+        src += open(f).read()
+    read = set(re.findall(r'env_int\("(LSL_[A-Z0-9_]+)"', src)) | set(re.findall(r'getenv\("(LSL_[A-Z0-9_]+)"', src))
+    for f in glob.glob(os.path.join(ROOT, "lam_slide_amd", "*.py")):
+        read |= set(re.findall(r'os\.environ(?:\.get)?\(\s*"(LSL_[A-Z0-9_]+)"', open(f).read()))
+    read -= {"LSL_FORCE_BUILD", "LSL_VERBOSE"}  # (build-time only, __graft_entry__.py)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("## 6. Runtime switches"):]
+    listed = set(re.findall(r"^\| `(LSL_[A-Z0-9_]+)", table, flags=re.M))
+    assert read == listed, (sorted(read - listed), sorted(listed - read))
+    assert subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", "gpu.sh")]).returncode == 0
