@@ -263,8 +263,9 @@ def test_sde_samplers_with_stored_noise(golden, dev):
 
 
 def test_cfg1_decoded_coordinates(golden, dev):
-    """BASELINE config 1 shape (T=30, L=192, D=256, H=16, depth 4; 10 Euler updates): final latents decoded by the
-    frozen stage-1 decoder (oracle restatement, CPU) must match the reference path within 1e-3 relative L2."""
+    """BASELINE config 1 (T=30, L=192, D=256, H=16, depth 4; 10 Euler updates; batch 4): final latents decoded by the frozen stage-1
+    decoder (oracle restatement, CPU) must match the reference path's own output (fixture F4_cfg1) within 1e-3 relative L2, at batch 1 and -
+    through bit-equality of the trajectory inside a batch of 4 - at the stated batch."""
     from lam_slide_amd import CreateTransport, SecondStageSampler
     from oracle import harness, latent_net
     f = golden("f4_cfg1.npz")
@@ -286,6 +287,16 @@ def test_cfg1_decoded_coordinates(golden, dev):
     pos_err = rel_l2(pos_got, pos_want)
     parity("cfg1.latents", lat_err, 5e-4)
     parity("cfg1.decoded_coords", pos_err, 3e-4)
+    # BASELINE configs[0] as stated: batch = 4.  Trajectory 0 = the reference-pinned one above, three more beside it: its bits in the batch of 4
+    # are those of the batch of 1 (so the reference comparison above holds for the batch-4 call), and every trajectory of the batch equals
+    # the same trajectory sampled alone.
+    g = torch.Generator().manual_seed(77)
+    lat4 = torch.cat([lat, torch.randn(3, 30, 192, 32, generator=g)]).to(dev)
+    init4 = torch.cat([init, torch.randn(3, 30, 192, 32, generator=g)]).to(dev)
+    got4 = drv.sample_latents(lat4, init=init4).cpu()
+    assert torch.equal(got4[0], got[0])
+    for b in (1, 3):
+        assert torch.equal(got4[b], drv.sample_latents(lat4[b:b + 1], init=init4[b:b + 1]).cpu()[0])
 
 
 def test_batch_independence_and_chunking_bit_exact(dev):
