@@ -16,8 +16,12 @@ ones = torch.ones(1, device=dev, dtype=torch.int32)
 dist.all_reduce(ones, op=dist.ReduceOp.SUM)
 t = torch.tensor([1.25], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
+mine = torch.tensor([0.5, 0.0], device=dev, dtype=torch.float64)   # (bench.py: every rank's own step time, gathered by all ranks)
+every = [torch.empty_like(mine)]
+dist.all_gather(every, mine)
+assert torch.equal(every[0], mine)
 dist.barrier()
 torch.cuda.synchronize()
 assert torch.equal(out[0], x) and int(ones.item()) == 1 and float(t) == 1.25
-print("rccl single-rank: backend", dist.get_backend(), "gather / all_reduce / barrier ok")
+print("rccl single-rank: backend", dist.get_backend(), "gather / all_reduce / all_gather / barrier ok")
 dist.destroy_process_group()
