@@ -33,8 +33,9 @@ extern "C" {
 /* 2: lsl_sample_ex takes n_trace; linear1 biases are read in whole 256-feature tiles (b1 zero-padded to a multiple of 256 floats);
  *    lsl_sample_ex, lsl_debug_taps, lsl_build_info exist.
  * 3: lsl_rk_lincomb / lsl_rk_dense / lsl_rk_error_ratio exist (state arithmetic of the adaptive and fixed-grid Runge-Kutta samplers);
- *    no signature of version 2 changed. */
-#define LSL_VERSION 3
+ *    no signature of version 2 changed.
+ * 4: lsl_model_set_attention_mode exists (attention_linear, mmdit.py:58-72); nothing else changed. */
+#define LSL_VERSION 4
 
 typedef struct lsl_model lsl_model;
 
@@ -140,6 +141,12 @@ void lsl_model_destroy(lsl_model *m);
 
 /* Trajectories processed per pass (cache-residency knob); 0 = library default. */
 int lsl_model_set_chunk(lsl_model *m, int32_t trajectories_per_pass);
+
+/* ParallelMLPAttentionV2's attention_mode (mmdit.py:222-229, used at mmdit.py:247 -> attention(), mmdit.py:40-53): 0 = "scaled_dot_product"
+ * (the default of a new model, every shipped config), 1 = any other string = attention_linear (mmdit.py:58-72): q softmax over the head
+ * channels, k softmax over the positions, out = (q hd^-1/2) (k^T v).  Replaces the reference's constructor keyword; may be changed between
+ * calls (cached graphs are dropped).  Models in linear mode always take the general path (lsl_sampler_path == 0). */
+int lsl_model_set_attention_mode(lsl_model *m, int32_t mode);
 
 /* Trajectories the library processes per pass for a call of this size (<= B). */
 int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L);

@@ -46,6 +46,7 @@ struct lsl_model {
     lsl_weights w;
     std::vector<lsl_block_weights> blocks;
     bool has_weights = false;
+    bool attention_linear = false;  // lsl_model_set_attention_mode: attention_linear (mmdit.py:58-72) instead of softmax attention
     int chunk = 0;
     int HHD, F1, K2, MODW;
     // hipGraph cache of lsl_sample: a call whose arguments (pointers, sizes, step table) repeat is captured once and replayed; the

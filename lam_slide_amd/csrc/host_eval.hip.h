@@ -97,7 +97,8 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     }
     m->prof.begin(0, st);
 
-    const float premul = (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
+    // softmax attention: log2(e) / sqrt(head_dim) rides on q (the kernels use exp2); attention_linear takes the plain normalised, rotated q
+    const float premul = m->attention_linear ? 1.0f : (float)(1.4426950408889634 / std::sqrt((double)d.head_dim));
     // position of token n along the attended axis = (n / pdiv) % pmod, done with multiply-high in the epilogue: exact while
     // n * d < 2^32, and n < 2^18 (pass size) with d <= T or L
     const int pdiv = temporal ? L : 1, pmod = temporal ? T : L;
@@ -105,7 +106,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     if ((unsigned long long)n * (unsigned)std::max(pdiv, pmod) >= (1ull << 32)) return fail(-3, "pass too large for the position arithmetic");
     const bool lin1_ts = linear1_ts_ok(d.head_dim_pad, D, m->F1, m->HHD, n);
     const int npad = (n + 255) & ~255;
-    const bool planes = qkv_planes_ok(d.head_dim_pad, D, d.heads, temporal ? T : L, temporal != 0, lin1_ts);
+    const bool planes = !m->attention_linear && qkv_planes_ok(d.head_dim_pad, D, d.heads, temporal ? T : L, temporal != 0, lin1_ts);
     // head-major planes are addressed with 32-bit per-lane byte offsets over the whole q | k | v buffer (k_lin1.hip.h flush, k_attn.hip.h
     // stream requests): a pass set larger than that through lsl_model_set_chunk / LSL_CHUNK_TRAJ is refused, never wrapped
     if (planes && (unsigned long long)npad * 3ull * (unsigned)m->HHD * 2ull >= (1ull << 32)) return fail(-3, "pass too large for the q/k/v plane offsets (%d tokens: at most %llu with this model)", n, (unsigned long long)((1ull << 32) / (6ull * (unsigned)m->HHD)) - 256);
@@ -146,7 +147,10 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
         aa.S = T; aa.n_seq = bc * L; aa.inner = L; aa.outer_stride = T * L; aa.pos_stride = L;
     }
     m->prof.begin(2, st);
-    if (d.head_dim_pad == 32) launch_attention_t<32>(aa, st);
+    if (m->attention_linear) {
+        if (d.head_dim_pad == 32) launch_attention_linear_t<32>(aa, st);
+        else launch_attention_linear_t<16>(aa, st);
+    } else if (d.head_dim_pad == 32) launch_attention_t<32>(aa, st);
     else launch_attention_t<16>(aa, st);
     m->prof.end(2, st);
 
@@ -226,7 +230,7 @@ int prepare_pass(lsl_model *m, const Workspace &ws, const float *x_cond, const i
 bool resident_ok(const lsl_model *m, int T, int L) {
     static const int off = env_int("LSL_RESIDENT", 1) == 0;  // documented runtime switch: 0 = always the general path
     const lsl_model_desc &d = m->d;
-    return !off && d.hidden == RES_D && d.heads == RES_H && d.head_dim == RES_HD && d.head_dim_pad == RES_HD && d.mlp_dim == RES_M &&
+    return !off && !m->attention_linear && d.hidden == RES_D && d.heads == RES_H && d.head_dim == RES_HD && d.head_dim_pad == RES_HD && d.mlp_dim == RES_M &&
            d.in_dim <= RES_MAX_C && d.in_dim % 4 == 0 && 2 * d.depth <= RES_MAX_BLOCKS && (long)T * L <= 48 && T <= 32 && L <= 32;
 }
 

@@ -463,6 +463,12 @@ bool launch_attention_stream(const AttnArgs &a_in, hipStream_t st) {
 }
 
 template <int HDP>
+void launch_attention_linear_t(const AttnArgs &a, hipStream_t st) {
+    const long units = (long)a.n_seq * a.H;
+    hipLaunchKernelGGL((k_attention_linear<HDP>), dim3((unsigned)std::min<long>(units, 8L * device_cus())), dim3(256), 0, st, a);
+}
+
+template <int HDP>
 void launch_attention_t(const AttnArgs &a, hipStream_t st) {
     if (launch_attention_stream<HDP>(a, st)) return;
     const int Sp = (a.S + 31) & ~31;

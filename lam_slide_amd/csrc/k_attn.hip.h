@@ -789,3 +789,114 @@ __global__ void __launch_bounds__(256) k_attention_tiny(AttnArgs a) {
         *reinterpret_cast<u32x4 *>(dst + 8 * c) = w;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// attention_mode other than "scaled_dot_product" (mmdit.py:50-53 -> attention_linear, mmdit.py:58-72; no shipped config selects it):
+//   q <- softmax over the head channels, k <- softmax over the POSITIONS of the sequence (per channel), q <- q hd^-1/2,
+//   context[d][e] = sum_n k[n][d] v[n][e],   out[n][e] = sum_d q[n][d] context[d][e]
+// on the normalised + rotated q / k that linear1 leaves (bf16, q WITHOUT the softmax pre-multiplier: the host passes 1).  One 256-thread
+// workgroup per (sequence, head), fp32 throughout, three passes over the unit's rows (L2-resident): channel maxima of k; the context
+// (positions staged 64 at a time as exp(k - max) | v, a thread owns HDP^2 / 256 context entries); the outputs (a thread owns a position).
+// S^2 never appears: 2 S hd^2 multiply-adds per unit.  Padded channels (hd < HDP) hold zeros in q / k / v and take no part in either softmax.
+template <int HDP>
+__global__ void __launch_bounds__(256) k_attention_linear(AttnArgs a) {
+    constexpr int CH = 64, EPT = HDP * HDP / 256, TPD = HDP / EPT, G = 256 / HDP, VPR = HDP / 8;
+    __shared__ float Ke[CH][HDP + 1], Vs[CH][HDP + 4], ctx[HDP][HDP + 1], red[G][HDP], kmx[HDP];
+    const int tid = threadIdx.x, S = a.S, hd = a.hd;
+    const size_t rs = 3 * (size_t)a.HHD;
+    const float qscale = rsqrtf((float)hd);
+    for (long u = blockIdx.x; u < (long)a.n_seq * a.H; u += gridDim.x) {
+        const int seq = (int)(u / a.H), head = (int)(u % a.H);
+        const size_t tok0 = (size_t)(seq / a.inner) * a.outer_stride + (seq % a.inner);
+        const u16 *base = a.qkv + tok0 * rs + head * HDP;  // q of position 0; k at + HHD, v at + 2 HHD; position n at + n pos_stride rs
+        {  // channel maxima of k over the positions
+            const int d = tid % HDP, g = tid / HDP;
+            float m = -INFINITY;
+            for (int n = g; n < S; n += G) m = fmaxf(m, bf2f(base[a.HHD + (size_t)n * a.pos_stride * rs + d]));
+            red[g][d] = m;
+            __syncthreads();
+            if (tid < HDP) {
+#pragma unroll
+                for (int j = 1; j < G; ++j) m = fmaxf(m, red[j][tid]);  // (tid < HDP: g == 0, m = red[0][tid])
+                kmx[tid] = m;
+            }
+            __syncthreads();
+        }
+        const int d = tid / TPD, e0 = (tid % TPD) * EPT;
+        float acc[EPT], zsum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) acc[j] = 0.0f;
+        for (int c0 = 0; c0 < S; c0 += CH) {
+            for (int i = tid; i < CH * VPR; i += 256) {  // 8 channels of one position per item
+                const int p = i / VPR, c8 = 8 * (i % VPR), n = c0 + p;
+                u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+                if (n < S) {
+                    const u16 *row = base + (size_t)n * a.pos_stride * rs + c8;
+                    kw = *reinterpret_cast<const u32x4 *>(row + a.HHD);
+                    vw = *reinterpret_cast<const u32x4 *>(row + 2 * a.HHD);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c8 + 2 * k;
+                    const float k0 = __uint_as_float(kw[k] << 16), k1 = __uint_as_float(kw[k] & 0xffff0000u);
+                    Ke[p][c] = (n < S && c < hd) ? __expf(k0 - kmx[c]) : 0.0f;
+                    Ke[p][c + 1] = (n < S && c + 1 < hd) ? __expf(k1 - kmx[c + 1]) : 0.0f;
+                    Vs[p][c] = __uint_as_float(vw[k] << 16);
+                    Vs[p][c + 1] = __uint_as_float(vw[k] & 0xffff0000u);
+                }
+            }
+            __syncthreads();
+            const int np = min(CH, S - c0);
+            for (int p = 0; p < np; ++p) {
+                const float kv = Ke[p][d];
+                zsum += kv;
+#pragma unroll
+                for (int j = 0; j < EPT; ++j) acc[j] = fmaf(kv, Vs[p][e0 + j], acc[j]);
+            }
+            __syncthreads();
+        }
+        {
+            const float inv = zsum > 0.0f ? 1.0f / zsum : 0.0f;  // (padded channels: every term is zero)
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) ctx[d][e0 + j] = acc[j] * inv;
+        }
+        __syncthreads();
+        for (int n = tid; n < S; n += 256) {
+            const u16 *row = base + (size_t)n * a.pos_stride * rs;
+            float q[HDP], o[HDP];
+#pragma unroll
+            for (int c = 0; c < VPR; ++c) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(row + 8 * c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    q[8 * c + 2 * k] = __uint_as_float(w[k] << 16);
+                    q[8 * c + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+                }
+            }
+            float m = -INFINITY, sum = 0.0f;
+#pragma unroll
+            for (int c = 0; c < HDP; ++c)
+                if (c < hd) m = fmaxf(m, q[c]);
+#pragma unroll
+            for (int c = 0; c < HDP; ++c) {
+                q[c] = c < hd ? __expf(q[c] - m) : 0.0f;
+                sum += q[c];
+                o[c] = 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < HDP; ++c) {
+#pragma unroll
+                for (int e = 0; e < HDP; ++e) o[e] = fmaf(q[c], ctx[c][e], o[e]);
+            }
+            const float sc = qscale / sum;
+            u16 *dst = a.z + (tok0 + (size_t)n * a.pos_stride) * a.zw + head * HDP;
+#pragma unroll
+            for (int c = 0; c < VPR; ++c) {
+                const u32x4 w = {pack2(o[8 * c] * sc, o[8 * c + 1] * sc), pack2(o[8 * c + 2] * sc, o[8 * c + 3] * sc),
+                                 pack2(o[8 * c + 4] * sc, o[8 * c + 5] * sc), pack2(o[8 * c + 6] * sc, o[8 * c + 7] * sc)};
+                *reinterpret_cast<u32x4 *>(dst + 8 * c) = w;
+            }
+        }
+        __syncthreads();  // ctx, red and kmx are rewritten by the next unit
+    }
+}

@@ -161,6 +161,17 @@ int lsl_model_set_chunk(lsl_model *m, int32_t c) try {
     return fail(-11, "unexpected C++ exception");
 }
 
+int lsl_model_set_attention_mode(lsl_model *m, int32_t mode) try {
+    if (!m || (mode != 0 && mode != 1)) return fail(-1, "attention mode must be 0 (scaled_dot_product) or 1 (linear)");
+    m->attention_linear = mode == 1;
+    drop_graphs(m);
+    return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
+}
+
 int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
     if (!m || B <= 0 || T <= 0 || L <= 0) return 0;
     return default_chunk(m, B, T, L);

@@ -94,10 +94,9 @@ class LatentSIV3(nn.Module):
         self.n_timesteps = n_timesteps      # accepted and ignored, as in the reference
         self.checkpointing = checkpointing  # idem (inference path)
         self.normalize = normalize
+        # mmdit.py:50-53: "scaled_dot_product" is softmax attention, ANY other string selects attention_linear (mmdit.py:58-72); every
+        # shipped config uses the former (configs/model/*/second-stage.yaml)
         self.attention_mode = attention_mode
-        if attention_mode != "scaled_dot_product":
-            # every shipped config uses SDPA (configs/model/*/second-stage.yaml); "linear" (mmdit.py:58-72) is not built
-            raise NotImplementedError(f"attention_mode {attention_mode!r} is not implemented by the HIP path")
         self.dims = make_dims(depth, in_dim, hidden_size, num_heads, mlp_ratio, vec_in_dim, normalize, theta)
         self.depth, self.share_weights = depth, share_weights
         mlp_dim = self.dims.mlp_dim
@@ -178,6 +177,8 @@ class LatentSIV3(nn.Module):
             _lib.check(lib.lsl_model_set_weights(self._handle, C.byref(self._packed.c_weights)))
             if self._chunk:
                 lib.lsl_model_set_chunk(self._handle, self._chunk)
+            if self.attention_mode != "scaled_dot_product":
+                _lib.check(lib.lsl_model_set_attention_mode(self._handle, 1))
         return self._packed
 
     def set_chunk(self, trajectories_per_pass: int):

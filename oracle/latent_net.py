@@ -40,6 +40,7 @@ class NetShape:
     theta: int = 10_000
     normalize: bool = False
     share_weights: bool = False
+    attention_mode: str = "scaled_dot_product"  # anything else selects attention_linear (mmdit.py:50-53)
 
     @property
     def head_dim(self) -> int:
@@ -112,8 +113,14 @@ def attn_mlp_block(p: Dict[str, Tensor], pre: str, u: Tensor, cos: Tensor, sin: 
         taps[tag + "z"] = z
         taps[tag + "q_norm"], taps[tag + "k_norm"] = q, k
     q, k = rotate_pairs(q, cos, sin), rotate_pairs(k, cos, sin)
-    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
-    a = torch.matmul(torch.softmax(s, dim=-1), v)  # G H S hd
+    if sh.attention_mode == "scaled_dot_product":
+        s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
+        a = torch.matmul(torch.softmax(s, dim=-1), v)  # G H S hd
+    else:
+        # attention_linear (mmdit.py:58-72): q softmax over the head channels, k softmax over the positions, q scaled by hd^-1/2,
+        # context[d][e] = sum_n k[n][d] v[n][e], out[n][e] = sum_d q[n][d] context[d][e]
+        context = torch.matmul(torch.softmax(k, dim=-2).transpose(-1, -2), v)  # G H hd hd
+        a = torch.matmul(torch.softmax(q, dim=-1) * hd ** -0.5, context)     # G H S hd
     a = a.permute(0, 2, 1, 3).reshape(G, S, D)
     if taps is not None:
         taps[tag + "q_rope"], taps[tag + "k_rope"] = q, k

@@ -31,7 +31,7 @@ def build_net(sh, params, dev):
     from lam_slide_amd import LatentSIV3
     net = LatentSIV3(depth=sh.depth, in_dim=sh.in_dim, hidden_size=sh.hidden_size, num_heads=sh.num_heads,
                      vec_in_dim=sh.vec_in_dim, mlp_ratio=sh.mlp_ratio, theta=sh.theta, normalize=sh.normalize,
-                     share_weights=sh.share_weights, reset_parameters=False)
+                     share_weights=sh.share_weights, attention_mode=sh.attention_mode, reset_parameters=False)
     net.load_state_dict(params)
     return net.to(dev)
 
@@ -39,7 +39,7 @@ def build_net(sh, params, dev):
 def test_library_loaded_and_fails_loudly_on_cpu(dev):
     from lam_slide_amd import LatentSIV3, _lib
     lib = _lib.load()
-    assert lib.lsl_version() == _lib.ABI_VERSION == 3
+    assert lib.lsl_version() == _lib.ABI_VERSION == 4
     net = LatentSIV3(depth=1, in_dim=8, hidden_size=64, num_heads=4, reset_parameters=False)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 2, 3, 8), torch.zeros(1), torch.zeros(1, 2, 3, 8), torch.zeros(1, 2, 3, dtype=torch.long))
@@ -123,6 +123,62 @@ def test_forward_shape_classes(golden, dev):
         y = g.get("y")
         out = net(g["x"].to(dev), g["t"].to(dev), g["x_cond"].to(dev), g["mask"].to(dev), y.to(dev) if y is not None else None)
         parity(f"f2.{n}", rel_l2(out.cpu(), g["out"]), 6e-4)
+
+
+def test_linear_attention_mode_against_reference_outputs(golden, dev):
+    """attention_mode="linear" (mmdit.py:58-72): F10 = outputs of the reference module built with that mode (hd 16 / 24 padded / 32, axes
+    of 2 .. 300 positions, normalize, y)."""
+    import dataclasses
+    from lam_slide_amd import _lib
+    from oracle import latent_net
+    f = golden("f10_linear_attention.npz")
+    for n in sorted({k.split("/")[0] for k in f.raw.files}):
+        g = f.group(n)
+        sh = dataclasses.replace(shape_from({k[6:]: v for k, v in g.items() if k.startswith("shape.")}), attention_mode="linear")
+        net = build_net(sh, latent_net.random_params(sh, seed=int(g["weight_seed"])), dev)
+        y = g.get("y")
+        out = net(g["x"].to(dev), g["t"].to(dev), g["x_cond"].to(dev), g["mask"].to(dev), y.to(dev) if y is not None else None)
+        parity(f"f10.{n}", rel_l2(out.cpu(), g["out"]), 6e-4)
+        assert _lib.load().lsl_sampler_path(net._handle, 4, 2) == 0
+
+
+@pytest.mark.parametrize("kw,T,L", [
+    (dict(depth=1, in_dim=8, hidden_size=64, num_heads=4, mlp_ratio=2), 70, 6),                          # tile-GEMM linear1, 16-wide heads
+    (dict(depth=1, in_dim=16, hidden_size=384, num_heads=16, mlp_ratio=4), 33, 2),                       # 24 -> 32 padded heads
+    (dict(depth=1, in_dim=32, hidden_size=512, num_heads=16, mlp_ratio=2), 3, 300),                      # token-stationary linear1, S > 256
+    (dict(depth=1, in_dim=32, hidden_size=128, num_heads=4, mlp_ratio=2, vec_in_dim=16), 20, 2),         # the trajectory-resident shape
+], ids=["d64", "d384", "d512", "d128_resident_shape"])
+def test_linear_attention_mode_stage_taps_and_sampler(kw, T, L, dev):
+    """attention_linear stage by stage against the pinned oracle's taps (q / k WITHOUT the softmax pre-multiplier, the context product),
+    then a 5-update Euler solve through lsl_sample (graph replay included) against the oracle's sampler."""
+    from lam_slide_amd import _lib
+    from oracle import harness, latent_net, transport as otr
+    sh = latent_net.NetShape(**kw, attention_mode="linear")
+    p = latent_net.random_params(sh, seed=41)
+    net = build_net(sh, p, dev)
+    net.ensure_packed(dev)
+    B, C, D = 2, kw["in_dim"], kw["hidden_size"]
+    g = torch.Generator().manual_seed(5)
+    x, xc = torch.randn(B, T, L, C, generator=g), torch.randn(B, T, L, C, generator=g)
+    mask = (torch.rand(B, T, L, generator=g) > 0.5).long()
+    t = torch.rand(B, generator=g)
+    y = torch.randn(B, sh.vec_in_dim, generator=g) if sh.vec_in_dim else None
+    taps = {}
+    latent_net.forward(p, sh, x, t, xc, mask, y, taps=taps)
+    mods = torch.cat([taps[f"l{i}.mod"] for i in range(sh.depth)] + [taps["final_mod"].reshape(B, 2 * D)], dim=1).to(dev).contiguous()
+    g1 = taps["l0.mod"][:, 2 * D:3 * D][:, None, None, :]
+    h_states = [taps["h0"], taps["h0"] + g1 * taps["l0.sp.out"].reshape(B, T, L, D)]
+    _check_stage_taps(f"linear_taps.{D}", net, _lib.load(), sh, taps, h_states, mods, B, T, L, dev,
+                      dict(q=1.5e-2, k=1.5e-2, v=1.5e-2, attn=1.5e-2, gelu=1.5e-2))
+    assert _lib.load().lsl_sampler_path(net._handle, T, L) == 0  # linear mode never takes the trajectory-resident kernel
+    s = _sampler(net)
+    fn = s.get_sample_fn("ODE", {"sampling_method": "euler", "num_steps": 6})
+    kwargs = dict(x_cond=xc.to(dev), x_cond_mask=mask.to(dev), **({"y": y.to(dev)} if y is not None else {}))
+    first = fn(x.to(dev), net.forward, **kwargs)[-1].cpu()
+    again = fn(x.to(dev), net.forward, **kwargs)[-1].cpu()  # second appearance of the argument set: captured / replayed
+    assert s.last_path == "fused" and torch.equal(first, again)
+    want = harness.sample_latents(p, sh, otr.Transport("GVP", "data"), x, xc, mask, y, "ODE", {"sampling_method": "euler", "num_steps": 6})
+    parity(f"linear_sample.{D}", rel_l2(first, want), 1e-3)
 
 
 def _sampler(net, path="GVP", pred="data", **kw):
@@ -817,7 +873,7 @@ def _check_stage_taps(name, net, lib, sh, taps, h_states, mods, B, T, L, dev, ba
     import math
     from oracle import latent_net
     D, H, hd = sh.hidden_size, sh.num_heads, sh.head_dim
-    premul = 1.4426950408889634 / math.sqrt(hd)
+    premul = 1.4426950408889634 / math.sqrt(hd) if sh.attention_mode == "scaled_dot_product" else 1.0  # (attention_linear: plain q)
     worst = {}
     for i in range(sh.depth):
         for bi, tag in ((2 * i, f"l{i}.sp."), (2 * i + 1, f"l{i}.tm.")):

@@ -35,6 +35,22 @@ def test_f2_shape_classes(golden):
         assert rel_l2(out, g["out"]) < 2e-6, n
 
 
+def test_f10_linear_attention_mode(golden):
+    """attention_mode="linear" (mmdit.py:58-72): outputs of the reference module built with that mode; the softmax form must NOT match them."""
+    import dataclasses
+    f = golden("f10_linear_attention.npz")
+    names = sorted({k.split("/")[0] for k in f.raw.files})
+    assert len(names) == 3
+    for n in names:
+        g = f.group(n)
+        sdpa = shape_from({k[6:]: v for k, v in g.items() if k.startswith("shape.")})
+        sh = dataclasses.replace(sdpa, attention_mode="linear")
+        p = latent_net.random_params(sh, seed=int(g["weight_seed"]))
+        args = (g["x"], g["t"], g["x_cond"], g["mask"], g.get("y"))
+        assert rel_l2(latent_net.forward(p, sh, *args), g["out"]) < 2e-6, n
+        assert rel_l2(latent_net.forward(p, sdpa, *args), g["out"]) > 5e-3, n
+
+
 def test_f3_transport_scalars(golden):
     f = golden("f3_transport.npz")
     t, x, mo = f["t"], f["x"], f["model_out"]

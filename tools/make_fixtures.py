@@ -497,7 +497,36 @@ def f9():
         meta=np.array([F["B"], F["T"], F["A"], F["L"], F["cond_idx"][0], F["cond_idx"][1], F["num_steps"]]))
 
 
+# ------------------------------------------------------------------------------------------- F10
+F10_CASES = {
+    # attention_mode="linear" (mmdit.py:50-53, 58-72; no shipped config selects it).  name: (NetShape kwargs, B, T, L, weight seed)
+    "lin_hd16_s8x70": (dict(depth=2, in_dim=8, hidden_size=64, num_heads=4, mlp_ratio=2), 2, 70, 8, 31),
+    "lin_hd24_s2x33": (dict(depth=1, in_dim=12, hidden_size=192, num_heads=8, mlp_ratio=1), 1, 33, 2, 32),
+    "lin_hd32_s300x3_norm_y": (dict(depth=1, in_dim=16, hidden_size=128, num_heads=4, mlp_ratio=2, vec_in_dim=32, normalize=True), 2, 3, 300, 33),
+}
+
+
+def f10():
+    arrays = {}
+    for name, (kw, B, T, L, wseed) in F10_CASES.items():
+        sh = latent_net.NetShape(**kw, attention_mode="linear")
+        sd = latent_net.random_params(sh, seed=wseed)
+        m = LatentSIV3(depth=sh.depth, in_dim=sh.in_dim, hidden_size=sh.hidden_size, num_heads=sh.num_heads, vec_in_dim=sh.vec_in_dim,
+                       mlp_ratio=sh.mlp_ratio, theta=sh.theta, normalize=sh.normalize, attention_mode="linear", reset_parameters=False).eval()
+        m.load_state_dict(sd)
+        x, t, xc, mask, y = make_inputs(sh, B, T, L, 12)
+        with torch.no_grad():
+            out = m(x, t, xc, mask, y)
+        e = rel(latent_net.forward(sd, sh, x, t, xc, mask, y), out)
+        sdpa = rel(latent_net.forward(sd, latent_net.NetShape(**kw), x, t, xc, mask, y), out)
+        print(f"F10 {name}: oracle rel {e:.2e} (the softmax-attention oracle on the same weights: {sdpa:.2e})")
+        assert e < 2e-6 and sdpa > 1e-3
+        arrays[name] = dict(**{"shape." + k: v for k, v in shape_dict(sh).items()}, weight_seed=wseed,
+                            x=x, t=t, x_cond=xc, mask=mask, out=out, **({"y": y} if y is not None else {}))
+    npz("f10_linear_attention.npz", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
     for w in which:
         globals()[w]()
