@@ -78,7 +78,7 @@ struct Workspace {
     float *tf_all, *hid_all, *vec_all, *mods_all;
     int mods_group;  // records per group (0: class-conditioned model, tables per evaluation)
     u16 *a, *qkv, *z;
-    float *kmax2;  // [2 * depth]: bound of |k|^2 per attention block (k_rope_scaled), for k_attention_stream's softmax shift
+    float *kmax2;  // [4 * depth]: bound of |k|^2 per attention block (k_rope_scaled), then of |q|^2 without the softmax pre-multiplier (same order): k_attention_stream's softmax shift
     u16 *w2p;  // linear2 weights of every sub-block in the fragment order of k_linear2_ws (k_lin2_pack, once per call), or NULL
     size_t bytes;
 };
@@ -102,7 +102,7 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.rope_t = (float2 *)take((size_t)T * (d.head_dim_pad / 2) * sizeof(float2));
     ws.rope_qk_stride = (size_t)std::max(T, L) * (d.head_dim_pad / 2);
     ws.rope_qk = (float4 *)take((size_t)4 * d.depth * ws.rope_qk_stride * sizeof(float4));
-    ws.kmax2 = (float *)take((size_t)2 * d.depth * sizeof(float));
+    ws.kmax2 = (float *)take((size_t)4 * d.depth * sizeof(float));
     ws.cond_emb = (float *)take(n * D * 4);
     ws.h = (float *)take(n * D * 4);
     ws.yemb = (float *)take((size_t)bc * D * 4);

@@ -74,7 +74,7 @@ void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream
             jobs.out[k] = ws.rope_qk + (size_t)t * ws.rope_qk_stride;
             jobs.scale[k] = (t & 1) ? m->blocks[bi].ks : m->blocks[bi].qs;
             jobs.n_pos[k] = (bi & 1) ? T : L;
-            jobs.sq_bound[k] = (t & 1) ? ws.kmax2 + bi : nullptr;
+            jobs.sq_bound[k] = ws.kmax2 + ((t & 1) ? 0 : nb) + bi;
             max_pos = std::max(max_pos, jobs.n_pos[k]);
         }
         hipLaunchKernelGGL(k_rope_scaled, dim3((max_pos * half + 255) / 256, jobs.n_jobs), dim3(256), 0, st, jobs, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
@@ -138,6 +138,8 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     aa.hd = d.head_dim;
     static const int attn_bound = tune_int("LSL_ATTN_BOUND", 1);
     aa.kmax2 = ws.kmax2 + bi;
+    aa.qmax2 = ws.kmax2 + 2 * d.depth + bi;
+    aa.premul = premul;
     aa.planes = planes ? 1 : 0;
     aa.npad = npad;
     aa.bound = attn_bound == 2 || (attn_bound == 1 && (temporal ? T : L) > 96);  // short axes: the max pass is one or two tiles, cheaper than the norms

@@ -30,6 +30,8 @@ struct AttnArgs {
     int bound;       // k_attention_rows: 1 = softmax shifted by the Cauchy-Schwarz bound |q| max|k| instead of the row maximum when that is safe
     int planes, npad;    // k_attention_stream (spatial): 1 = q / k / v are head-major planes qkv[section][head][npad tokens][HDP] (k_lin1.hip.h)
     const float *kmax2;  // k_attention_stream: device scalar, an upper bound of |k_j|^2 for every key of this block (head_dim max_d ks_d^2: k_rope_scaled)
+    const float *qmax2;  // k_attention_stream: the same bound for the queries BEFORE the softmax pre-multiplier `premul` (head_dim max_d qs_d^2)
+    float premul;
     int blk, n_tok;      // k_attention_stream SHORT, tiny spatial axes (round 5): blk > 0 = the launch presents 32 / blk consecutive sequences of blk
                          // positions (a power of two <= 16) as ONE 32-row sequence (S = 32, n_seq = tiles of 32 tokens): scores outside the
                          // block diagonal are masked; n_tok = valid tokens (rows of the last tile past it are not stored)
@@ -509,6 +511,9 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) zero[e] = 0.0f;
     const float kmax2 = a.kmax2 ? *a.kmax2 : 0.0f;
+    // the bound for EVERY query of the block, from the norm scales alone: |q_i| <= premul sqrt(qmax2) (RMS-normalised over head_dim, times scale,
+    // rotated).  At most 60 (the shipped models: 9 - 15): no per-query bound is computed at all (78 vector instructions per wave and unit)
+    const bool all_shifted = a.kmax2 && a.qmax2 && sqrtf(*a.qmax2 * kmax2) * a.premul * 1.02f <= 60.0f;  // (uniform)
     // tiny axes packed 32 / blk sequences to a tile (AttnArgs::blk): bit e of the lane = accumulator register e holds a key of the lane's own
     // sequence (key row acc_row(e, hf), query row r: same block of blk rows)
     constexpr bool grouped = PACK;  // (the host selects the instance: AttnArgs::blk > 0)
@@ -555,7 +560,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         const bool has_tile = !LONG || 256 * qg + 32 * wave < S;              // (uniform) LONG: wave w = query tile w of the group
         const bool more = u + ustep < u1;                                     // (uniform)
         float mx = -INFINITY;
-        bool shifted = false;
+        bool shifted = all_shifted;
         f32x16 o = zero, lsum = zero;
 #pragma unroll 1
         for (int c = 0; c < NC; ++c) {  // stage (u, c)
@@ -568,7 +573,7 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
                 request_q(u + ustep);
             }
             // softmax bound of this wave's queries (see above): decided once per unit, behind the barrier and the next stage's requests
-            if (c == 0 && has_tile && a.kmax2) {
+            if (c == 0 && has_tile && a.kmax2 && !all_shifted) {
                 float qq = 0.0f;
 #pragma unroll
                 for (int s2 = 0; s2 < KS; ++s2) {
