@@ -1,6 +1,6 @@
 """Random supported shapes through the HIP path against the CPU oracle (not part of the test suite: a sweep for edge cases of the kernel
 choices - ragged token counts, axes of every length class, every hidden size, shared / per-trajectory modulation):
-    python tools/fuzz_shapes.py [n_cases] [seed]
+    python tools/fuzz_shapes.py [n_cases] [seed] [attention_mode]      (attention_mode: scaled_dot_product (default) | linear | mixed)
 For each case: one forward evaluation and a 3-update fused ODE sampling call, relative L2 against the oracle; prints the worst cases."""
 import random
 import sys
@@ -22,6 +22,7 @@ def rel_l2(a, b):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    mode_arg = sys.argv[3] if len(sys.argv) > 3 else "scaled_dot_product"
     dev = torch.device("cuda:0")
     worst = []
     t_start = time.time()
@@ -42,6 +43,9 @@ def main():
         kw = dict(depth=depth, in_dim=C, hidden_size=D, num_heads=heads, mlp_ratio=mlp)
         if vec:
             kw["vec_in_dim"] = vec
+        mode = rng.choice(["scaled_dot_product", "linear"]) if mode_arg == "mixed" else mode_arg
+        if mode != "scaled_dot_product":
+            kw["attention_mode"] = mode
         try:
             sh = latent_net.NetShape(**kw)
             p = latent_net.random_params(sh, seed=case + 100)
@@ -73,7 +77,7 @@ def main():
             ref = otr.sample_ode(tro, init, model, num_steps=4, sampling_method="euler", x_cond=x_cond, x_cond_mask=m2)[-1]
             e_smp = rel_l2(res, ref)
         bad = not (e_fwd < 2e-3) or (e_smp == e_smp and not (e_smp < 2e-3))
-        print(f"case {case}: D={D} H={heads} mlp={mlp} C={C} vec={vec} depth={depth} B={B} T={T} L={L}: forward {e_fwd:.2e} sampler {e_smp:.2e}{'   <-- CHECK' if bad else ''}", flush=True)
+        print(f"case {case}: D={D} H={heads} mlp={mlp} C={C} vec={vec} depth={depth} B={B} T={T} L={L} {mode}: forward {e_fwd:.2e} sampler {e_smp:.2e}{'   <-- CHECK' if bad else ''}", flush=True)
         worst.append((max(e_fwd, e_smp if e_smp == e_smp else 0.0), case))
     worst.sort(reverse=True)
     print("worst:", worst[:5], f"({time.time() - t_start:.0f} s)")
