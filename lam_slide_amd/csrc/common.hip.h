@@ -56,6 +56,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The same sum as ONE value for the whole wave, by DPP moves only (row shifts inside the rows of 16 lanes, then row_bcast15 / row_bcast31 across
+// them; the total ends in lane 63 and comes back as a scalar): 6 vector adds + a v_readlane instead of 6 ds_bpermute round trips through the LDS
+// queue (wave_sum).  For kernels with few waves per SIMD, where those round trips are exposed.  A different summation tree than wave_sum's.
+#define LSL_DPP_ADD(v, ctrl, rows) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xF, false)))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = LSL_DPP_ADD(v, 0x111, 0xF);  // row_shr:1
+    v = LSL_DPP_ADD(v, 0x112, 0xF);  // row_shr:2
+    v = LSL_DPP_ADD(v, 0x114, 0xF);  // row_shr:4
+    v = LSL_DPP_ADD(v, 0x118, 0xF);  // row_shr:8: lane 15 of every row of 16 lanes now holds the row's sum
+    v = LSL_DPP_ADD(v, 0x142, 0xA);  // row_bcast15: rows 1 and 3 add the sum of the row before them
+    v = LSL_DPP_ADD(v, 0x143, 0xC);  // row_bcast31: rows 2 and 3 add the sum of rows 0 + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#undef LSL_DPP_ADD
+
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 
 // v + (value of lane ^ 32) as one VALU exchange (gfx950 v_permlane32_swap) + one add, instead of ds_bpermute through the LDS queue.

@@ -439,20 +439,20 @@ __device__ __forceinline__ void row_load(const float *row, int lane, float (&v)[
         for (int k = 0; k < NE; ++k) v[k] = row[lane + 64 * k];
     }
 }
-template <int NE>
+template <int NE, bool DPP = false>
 __device__ __forceinline__ void row_stats(const float (&v)[NE], float eps, float &mean, float &rstd) {
     constexpr float invD = 1.0f / (float)(NE * 64);
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < NE; ++k) s += v[k];
-    mean = wave_sum(s) * invD;
+    mean = (DPP ? wave_sum_dpp(s) : wave_sum(s)) * invD;
     float q = 0.0f;
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
         const float a = v[k] - mean;
         q += a * a;
     }
-    rstd = rsqrtf(wave_sum(q) * invD + eps);
+    rstd = rsqrtf((DPP ? wave_sum_dpp(q) : wave_sum(q)) * invD + eps);
 }
 
 // h <- LayerNorm_{eps}(h) in place (normalize=True models, latent_si_v31.py:173-174, eps 1e-5).
@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(256) k_head_step_mfma(float *x, float *out, co
         for (int i = 0; i < RPW; ++i) {
             const int n = min(n0 + wave + 4 * i, N - 1);
             float mean, rstd;
-            row_stats<NE>(v[i], 1e-6f, mean, rstd);
+            row_stats<NE, true>(v[i], 1e-6f, mean, rstd);  // (two waves per SIMD: the DPP form, the LDS-queue round trips of wave_sum were exposed)
             if (one_traj) {
 #pragma unroll
                 for (int k = 0; k < NE; ++k) As[(wave + 4 * i) * AS + row_col<NE, VEC>(lane, k)] = (v[i][k] - mean) * rstd * sc1[k] + sh[k];
