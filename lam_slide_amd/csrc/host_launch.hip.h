@@ -444,6 +444,7 @@ bool launch_attention_stream(const AttnArgs &a_in, hipStream_t st) {
     if (!mode || !a.kmax2) return false;
     const size_t lds = (size_t)2 * 2 * 256 * HDP * 2 + (size_t)8 * 32 * HDP * 2;  // two images of K | V, 256 rows each; a 32-row query image per wave
     const long n_units = is_long ? (long)a.n_seq * a.H * (((a.S + 31) / 32 + 7) / 8) : (long)a.n_seq * (a.H / 8);  // LONG: (sequence, head, group of 8 query tiles)
+    if (n_units + 2L * device_cus() >= (1L << 31)) return false;  // (the kernel counts units in 32 bits)
     const int grid = (int)std::min<long>(2L * device_cus(), n_units);  // two workgroups per CU (2 x 80 KiB of LDS at 32-wide heads)
     // plain stores: behind streaming stores the in-order vector-memory queue reports the next unit's requests late (measured: 0.78 vs 0.27 ms)
     AttnArgs b = a;

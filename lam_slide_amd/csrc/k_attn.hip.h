@@ -396,12 +396,14 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
     const int nkt_last = LONG ? (rows_last + 31) >> 5 : 1;          // key tiles of the last chunk
     const int qrows_last = S - 256 * (QG - 1);                      // query rows of the last group
     const int hgroups = a.H >> 3;
-    const long n_units = LONG ? (long)a.n_seq * a.H * QG : (long)a.n_seq * hgroups;
+    // (32-bit unit arithmetic: the host keeps launches of 2^31 units and more off this kernel; 64-bit divisions by run-time values cost ~ 75
+    // scalar instructions each in front of every unit's requests)
+    const unsigned n_units = LONG ? (unsigned)a.n_seq * a.H * QG : (unsigned)a.n_seq * hgroups;
     // units are dealt round-robin over the workgroups in XCD-contiguous order: neighbouring units - the query groups of one (sequence, head),
     // which read the same keys, and neighbouring heads, whose 64-byte row pieces share 128-byte lines - run at the same time on one XCD and
     // meet in its L2 (with a contiguous range per workgroup the second head of a line came one unit-time later, after the line had left the
     // L2: FETCH_SIZE 1.38 GB per launch for 0.755 GB of rows)
-    const long ustep = gridDim.x, u0 = xcd_remap(blockIdx.x, gridDim.x), u1 = n_units;
+    const unsigned ustep = gridDim.x, u0 = xcd_remap(blockIdx.x, gridDim.x), u1 = n_units;
     if (u0 >= u1) return;  // (uniform)
     const unsigned rs = 3u * a.HHD;
     const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))(smem);
@@ -426,16 +428,17 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         if (!XL && !PACK) cst_kv[k] += pos_bytes * (unsigned)min(row_kv[k], S - 1);  // (packed tiny axes: clamped per unit, below)
     }
 
-    auto unit_tok0 = [&](long u, int &head0, int &qg) __attribute__((always_inline)) {
-        long sh = u;
+    auto unit_tok0 = [&](unsigned u, int &head0, int &qg) __attribute__((always_inline)) {
+        unsigned sh = u;
         qg = 0;
         if (LONG && QG > 1) {  // (uniform)
-            sh = u / QG;
-            qg = (int)(u - sh * QG);
+            sh = u / (unsigned)QG;
+            qg = (int)(u - sh * (unsigned)QG);
         }
-        const int seq = LONG ? (int)(sh / a.H) : (int)(sh / hgroups);
-        head0 = LONG ? (int)(sh % a.H) : 8 * (int)(sh % hgroups);
-        return (size_t)(seq / a.inner) * a.outer_stride + (seq % a.inner);
+        const unsigned hdiv = LONG ? (unsigned)a.H : (unsigned)hgroups, seq = sh / hdiv, hidx = sh - seq * hdiv;
+        head0 = LONG ? (int)hidx : 8 * (int)hidx;
+        const unsigned so = seq / (unsigned)a.inner;
+        return (size_t)so * a.outer_stride + (seq - so * (unsigned)a.inner);
     };
     // (wave-uniform by construction; the readfirstlanes make it provable for the "s" operands of the asm statements)
     auto uni_ptr = [](const char *q) __attribute__((always_inline)) {
@@ -458,9 +461,9 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         if (!XL && !PACK) cst_qt[k] += pos_bytes * (unsigned)min((LONG ? 32 * wave : 0) + R, S - 1);
     }
     // K | V rows of key chunk c of unit u -> image SET
-    auto request_kv = [&](long u, int c, int SET) __attribute__((always_inline)) {
-        int head0, qg;
-        const size_t tok0 = unit_tok0(u, head0, qg) + (size_t)(256 * c) * a.pos_stride;
+    // (a unit's first token, head and query group are computed ONCE - when its requests are issued, one unit ahead - and carried)
+    auto request_kv = [&](size_t unit_tok, int head0, int c, int SET) __attribute__((always_inline)) {
+        const size_t tok0 = unit_tok + (size_t)(256 * c) * a.pos_stride;
         const char *base = uni_ptr(reinterpret_cast<const char *>(a.qkv) +
                                    (planes ? 2 * (((size_t)head0 * a.npad + tok0) * HDP) : 2 * (tok0 * rs + (size_t)head0 * HDP)));
         const bool last = c == NC - 1;  // (uniform)
@@ -477,9 +480,8 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         }
     };
     // the wave's query tile of unit u -> its private image
-    auto request_q = [&](long u) __attribute__((always_inline)) {
-        int head0, qg;
-        const size_t tok0 = unit_tok0(u, head0, qg) + (size_t)(256 * qg) * a.pos_stride;
+    auto request_q = [&](size_t unit_tok, int head0, int qg) __attribute__((always_inline)) {
+        const size_t tok0 = unit_tok + (size_t)(256 * qg) * a.pos_stride;
         const char *base = uni_ptr(reinterpret_cast<const char *>(a.qkv) +
                                    (planes ? 2 * (((size_t)head0 * a.npad + tok0) * HDP) : 2 * (tok0 * rs + (size_t)head0 * HDP)));
         const bool last = qg == QG - 1;  // (uniform)
@@ -543,19 +545,21 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
         for (int s2 = 0; s2 < KS; ++s2) q[s2] = as_bf16x8(*reinterpret_cast<const u32x4 *>(qimg + k_swz<HDP>(r, 2 * s2 + hf)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in registers before anything else is written to the image
     };
-    request_kv(u0, 0, 0);
-    request_q(u0);
+    int nx_head0, nx_qg;
+    size_t nx_tok0 = unit_tok0(u0, nx_head0, nx_qg);
+    request_kv(nx_tok0, nx_head0, 0, 0);
+    request_q(nx_tok0, nx_head0, nx_qg);
     wait_vmcnt<0>();
     patch_ones(0);
     bf16x8 qn[KS];
     read_q(qn);
     int buf = 0;
-    for (long u = u0; u < u1; u += ustep) {
+    for (unsigned u = u0; u < u1; u += ustep) {
         bf16x8 qf[KS];
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) qf[s2] = qn[s2];
-        int head0, qg;
-        const size_t tok0 = unit_tok0(u, head0, qg);
+        const int head0 = nx_head0, qg = nx_qg;
+        const size_t tok0 = nx_tok0;
         const bool last_g = qg == QG - 1;                                     // (uniform)
         const bool has_tile = !LONG || 256 * qg + 32 * wave < S;              // (uniform) LONG: wave w = query tile w of the group
         const bool more = u + ustep < u1;                                     // (uniform)
@@ -567,10 +571,11 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
             __builtin_amdgcn_s_barrier();  // every wave's rows of this stage have landed (each waited for its own); every wave has left the other image
             asm volatile("" ::: "memory");
             const bool last_c = c == NC - 1;  // (uniform)
-            if (!last_c) request_kv(u, c + 1, buf ^ 1);
+            if (!last_c) request_kv(tok0, head0, c + 1, buf ^ 1);
             else if (more) {
-                request_kv(u + ustep, 0, buf ^ 1);
-                request_q(u + ustep);
+                nx_tok0 = unit_tok0(u + ustep, nx_head0, nx_qg);
+                request_kv(nx_tok0, nx_head0, 0, buf ^ 1);
+                request_q(nx_tok0, nx_head0, nx_qg);
             }
             // softmax bound of this wave's queries (see above): decided once per unit, behind the barrier and the next stage's requests
             if (c == 0 && has_tile && a.kmax2 && !all_shifted) {
