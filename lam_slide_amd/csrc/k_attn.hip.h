@@ -665,18 +665,8 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
                 if (shifted) {
                     if (!LONG) tile(0, scores(0, zero));
                     else if (!XL) {
-#if defined(LSL_ATTN_PIPE) && LSL_ATTN_PIPE
-                        f32x16 t = scores(0, zero);
-#pragma unroll 2
-                        for (int kt = 0; kt < nkt; ++kt) {  // the scores of tile kt + 1 are in the matrix pipe while tile kt's exponentials issue
-                            const f32x16 tn = scores(kt + 1 < nkt ? kt + 1 : kt, zero);
-                            tile(kt, t);
-                            t = tn;
-                        }
-#else
 #pragma unroll 2
                         for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, zero));  // (fully unrolled, hipcc hoists every fragment address and spills)
-#endif
                     } else {
 #pragma unroll LSL_ATTN_XL_UNROLL
                         for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, zero));
