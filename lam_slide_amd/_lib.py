@@ -105,6 +105,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+class LibraryMissing(RuntimeError):
+    """liblamslide_hip.so has not been built (the only failure a caller may treat as "no library": anything else - a HIP error, an
+    out-of-memory condition - propagates)."""
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -114,7 +119,7 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        raise LibraryMissing(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the HIP extension is the only compute path of lam_slide_amd)")
     lib = C.CDLL(LIB_PATH)
     lib.lsl_version.restype = C.c_int

@@ -128,7 +128,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     }
     m->prof.end(0, st);
     static const int nt_mask = tune_int("LSL_NT", 3);
-    AttnArgs aa;
+    AttnArgs aa{};
     aa.nt = (nt_mask >> 2) & 1;
     aa.qkv = ws.qkv;
     aa.z = ws.z;

@@ -50,6 +50,9 @@ struct TailArgs {
     int N, M, zw;
     int mod_stride, tpt;  // tokens per trajectory
     unsigned tpt_magic;   // floor(2^32 / tpt) + 1 (0 when tpt == 1)
+#ifdef TAIL_STAMPS
+    unsigned long long *dbg;  // tools/tail_harness.hip only: cycle sums per workgroup and wave
+#endif
 };
 
 template <int D, int HHD, int NW>
@@ -61,7 +64,7 @@ struct TailCfg {
     static constexpr int CHF = D / 16;      // fragments per chunk
     static constexpr int CH = CHF * 1024;   // bytes per chunk
     static constexpr int CO = HHD / 32;     // chunks of the attention half
-    static constexpr int NS = CH <= 16384 ? 4 : 3;
+    static constexpr int NS = NW == 8 ? 4 : 3;  // two chunks in flight, one (two with the skewed half) in use
     static constexpr int PPW = CHF / NW;    // DMA instructions per wave and chunk
     static_assert(CHF % NW == 0, "whole DMA instructions per wave");
     static constexpr int RING = NS * CH, STAGE = NW * 4096;
@@ -106,13 +109,18 @@ __global__ void __launch_bounds__(256) k_tail_pack(u16 *out, const u16 *W1, cons
 }
 
 #ifndef TAIL_PD
-#define TAIL_PD 3  // A fragments requested this many MFMAs ahead
+#define TAIL_PD 0  // A fragments requested this many MFMAs ahead (0: 2 at two waves per SIMD, 6 at one)
+#endif
+#ifndef TAIL_SKEW
+#define TAIL_SKEW 1  // waves 4-7 of an 8-wave workgroup run one chunk behind waves 0-3 (their SIMD partners)
 #endif
 
 template <int D, int HHD, int NW>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
     using C = TailCfg<D, HHD, NW>;
-    constexpr int NT = C::NT, KS = C::KS, KZ = C::KZ, CHF = C::CHF, CH = C::CH, CO = C::CO, NS = C::NS, PPW = C::PPW, TT = C::TT, PD = TAIL_PD;
+    constexpr int NT = C::NT, KS = C::KS, KZ = C::KZ, CHF = C::CHF, CH = C::CH, CO = C::CO, NS = C::NS, PPW = C::PPW;
+    constexpr int PD = TAIL_PD ? TAIL_PD : (NW == 8 ? 2 : 6);
+    constexpr bool SKEW = TAIL_SKEW && NW == 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,10 +129,14 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
     char *const stage = smem + C::RING + wave * 4096;
     float *const b1_lds = reinterpret_cast<float *>(smem + C::RING + C::STAGE);
 
+    // Work = wave tiles of 32 tokens, cut evenly over the workgroups; a workgroup walks its range in rounds of NW wave tiles (one per wave).  In
+    // a last, partial round the waves without a tile only keep the ring going: with one active wave per SIMD the round is bound by half the
+    // MFMA work, so 2.5 rounds of work take about 2.6 round times, not 3.
     const int MB = g.M >> 5, NCH = CO + 2 * MB;
-    const int ntile = (g.N + TT - 1) / TT;
-    const int t0 = (int)((long)ntile * blockIdx.x / gridDim.x), t1 = (int)((long)ntile * (blockIdx.x + 1) / gridDim.x);
-    if (t0 >= t1) return;  // (uniform)
+    const int nwt = (g.N + 31) >> 5;
+    const int w0 = (int)((long)nwt * blockIdx.x / gridDim.x), w1 = (int)((long)nwt * (blockIdx.x + 1) / gridDim.x);
+    if (w0 >= w1) return;  // (uniform)
+    const int rounds = (w1 - w0 + NW - 1) / NW;
 
     for (int i = tid * 4; i < g.M; i += NW * 64 * 4) *reinterpret_cast<float4 *>(b1_lds + i) = *reinterpret_cast<const float4 *>(g.b1 + i);
 
@@ -155,26 +167,82 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
         c_src = c_src + 1 == NCH ? 0 : c_src + 1;
         slot_d = slot_d + 1 == NS ? 0 : slot_d + 1;
     };
-    int slot_c = 0;  // slot of the next chunk to compute
-    // head of a chunk step: the chunk has landed (it was requested NS - 1 steps ago; younger than it are the requests of the NS - 2 chunks
-    // behind it - extra younger operations only make the counted wait conservative), every wave has left the previous chunk: its slot is
-    // requested again
+    int slot_c = 0;  // slot of the next chunk this wave computes
+    // Barrier b of the workgroup: chunk b has landed (requested two barriers ago; younger than it are only the requests of chunk b + 1 - extra
+    // younger operations make the counted wait conservative, never wrong); the leading waves (all waves without the skew) compute chunk b
+    // behind it, the skewed half chunk b - 1; nobody reads chunk b - 2 (b - 1 without the skew) any more, and chunk b + 2 is requested into
+    // its slot.  Every wave passes the same barriers and issues at each of them.
+#ifdef TAIL_STAMPS
+    unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    unsigned long long st_t = stamp();
+    const unsigned long long st_begin = st_t;
+#define TAIL_ST(k) { const unsigned long long t_ = stamp(); st_sum[k] += t_ - st_t; st_t = t_; }
+#else
+#define TAIL_ST(k)
+#endif
     auto step_head = [&]() __attribute__((always_inline)) {
-        wait_vmcnt<(NS - 2) * PPW>();
+        TAIL_ST(9)
+        wait_vmcnt<PPW>();
+        TAIL_ST(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        TAIL_ST(1)
         issue();
+        TAIL_ST(2)
     };
+    auto next_slot = [&]() __attribute__((always_inline)) { slot_c = slot_c + 1 == NS ? 0 : slot_c + 1; };
     auto frag = [&](const char *sb, int f) __attribute__((always_inline)) { return as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + f * 1024)); };
 
-    for (int k = 0; k < NS - 1; ++k) issue();
+    issue();
+    issue();
     __syncthreads();  // bias table
+    const bool lag = SKEW && wave >= 4;  // (uniform)
+    if (lag) step_head();  // the skewed half starts one barrier late ...
 
     const int chunk = lane & 7, rowi = lane >> 3;
     const unsigned st0 = (unsigned)(size_t)(LDS_PTR(char))(stage);
+    // rows of a [tokens][K] bf16 matrix as MFMA B fragments (k_lin1.hip.h load_x / finish_x): whole 128-byte lines per 8 lanes (8 rows per
+    // instruction), then line by line through the wave's staging image into fragment order, in place: line j of every row holds the k-steps
+    // 4 j .. 4 j + 3; chunk c of row t sits at t 128 + 16 (c ^ ((t >> 1) & 7)), conflict-free for both accesses
+    auto load_rows = [&](auto &xreg, auto ks_c, const u16 *X, int n0, int stride) __attribute__((always_inline)) {
+        constexpr int NK = decltype(ks_c)::value;
+        const u16 *xr = X + (size_t)(n0 + rowi) * stride + 8 * chunk;
+#pragma unroll
+        for (int j = 0; j < NK / 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xreg[4 * j + q] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + (size_t)(8 * q) * stride + 64 * j));
+    };
+    auto finish_rows = [&](auto &xreg, auto ks_c) __attribute__((always_inline)) {
+        constexpr int NK = decltype(ks_c)::value;
+        const unsigned xw = st0 + rowi * 128, xr0 = st0 + r * 128;
+#pragma unroll
+        for (int j = 0; j < NK / 4; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<LDS_PTR(u32x4)>(xw + 1024 * q + (((chunk ^ ((rowi >> 1) + 4 * q)) & 7) << 4)) = as_u32x4(xreg[4 * j + q]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                xreg[4 * j + m] = as_bf16x8(*reinterpret_cast<const LDS_PTR(u32x4)>(xr0 + ((((2 * m + hf) ^ (r >> 1)) & 7) << 4)));
+        }
+    };
 
-    for (int tile = t0; tile < t1; ++tile) {
-        const int n_wave = tile * TT + wave * 32;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int wt = w0 + rd * NW + wave;
+        if (wt >= w1) {  // (uniform) no tile for this wave in the last round: pass the round's barriers, keep requesting
+            for (int c = 0; c < NCH; ++c) {
+                step_head();
+                next_slot();
+            }
+            continue;
+        }
+        const int n_wave = wt * 32;
         f32x16 out[NT];
 #pragma unroll
         for (int ft = 0; ft < NT; ++ft)
@@ -184,9 +252,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
         // ---- attention half: out^T += Wo z^T ----
         {
             bf16x8 zreg[KZ];
-            const u16 *zr = g.Z + (size_t)(n_wave + r) * g.zw + 8 * hf;
-#pragma unroll
-            for (int ks = 0; ks < KZ; ++ks) zreg[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(zr + 16 * ks));
+            load_rows(zreg, std::integral_constant<int, KZ>(), g.Z, n_wave, g.zw);
+            finish_rows(zreg, std::integral_constant<int, KZ>());
+            TAIL_ST(6)
 #pragma unroll
             for (int c = 0; c < CO; ++c) {
                 step_head();
@@ -199,17 +267,16 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
                     out[f >> 1] = mfma32(fr[f % PD], zreg[2 * c + (f & 1)], out[f >> 1]);
                     if (f + PD < CHF) fr[f % PD] = frag(sb, f + PD);
                 }
-                slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+                next_slot();
+                TAIL_ST(3)
             }
         }
 
         // ---- mlp: up-projection -> GELU in registers -> down-projection ----
         bf16x8 areg[KS];
-        {
-            const u16 *xr = g.A + (size_t)(n_wave + r) * D + 8 * hf;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) areg[ks] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + 16 * ks));
-        }
+        load_rows(areg, std::integral_constant<int, KS>(), g.A, n_wave, D);
+        finish_rows(areg, std::integral_constant<int, KS>());
+        TAIL_ST(6)
         f32x16 up0, up1;
         auto init_up = [&](f32x16 &a, int j) __attribute__((always_inline)) {
 #pragma unroll
@@ -249,7 +316,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (DO_MFMA) slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+            if (DO_MFMA) next_slot();
+            TAIL_ST(4)
         };
         auto step_down = [&](const u32x4 (&gw)[2]) __attribute__((always_inline)) {
             const char *sb = smem + slot_c * CH + lane * 16;
@@ -261,7 +329,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
                 out[f >> 1] = mfma32(fr[f % PD], as_bf16x8(gw[f & 1]), out[f >> 1]);
                 if (f + PD < CHF) fr[f % PD] = frag(sb, f + PD);
             }
-            slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+            next_slot();
+            TAIL_ST(5)
         };
         std::integral_constant<int, 0> I0;
         std::integral_constant<int, 1> I1;
@@ -369,6 +438,17 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
                 }
             }
         }
+        TAIL_ST(7)
+    }
+    if (SKEW && !lag) {  // ... and the leading half passes one more at the end: the same number of barriers for every wave
+        wait_vmcnt<PPW>();
+        __builtin_amdgcn_s_barrier();
     }
     wait_vmcnt<0>();  // the ring's run-ahead requests must not land in LDS after the workgroup has gone
+#ifdef TAIL_STAMPS
+    if (lane == 0 && g.dbg) {
+        st_sum[8] = stamp() - st_begin;
+        for (int k = 0; k < 10; ++k) g.dbg[((size_t)blockIdx.x * NW + wave) * 10 + k] = st_sum[k];
+    }
+#endif
 }

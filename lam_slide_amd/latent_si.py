@@ -161,7 +161,7 @@ class LatentSIV3(nn.Module):
 
     # ---- native handle ---------------------------------------------------------------------------------
     def _weights_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (str(device), self.attention_mode) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def ensure_packed(self, device) -> PackedWeights:
         key = self._weights_key(device)

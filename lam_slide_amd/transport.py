@@ -662,14 +662,15 @@ class Sampler:
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or out.requires_grad)  # (the library result carries no grad_fn)
         if x.is_cuda and x.dtype == torch.float32 and out.dtype == torch.float32 and out.shape == x.shape and not needs_grad:
             # one library launch instead of three element-wise kernels; the same two rounded products and their rounded sum
-            try:
-                ops = self._rk_ops.get(x.device)
-                if ops is None:
-                    ops = self._rk_ops[x.device] = _RkOps(x)
+            ops = self._rk_ops.get(x.device)
+            if ops is None:
+                try:
+                    ops = _RkOps(x)
+                except _lib.LibraryMissing:  # an arbitrary callable on a GPU needs no library: the torch expression below, same values
+                    ops = False              # (remembered per device; HIP errors and out-of-memory conditions propagate)
+                self._rk_ops[x.device] = ops
+            if ops:
                 v = ops.lincomb([(vx, x), (vm, out)])
-            except RuntimeError:  # no library (an arbitrary callable on a GPU needs none): the torch expression below, same values
-                if x.device in self._rk_ops:
-                    raise
         if v is None:
             v = vx * x + vm * out
         assert v.shape == x.shape, "Output shape from ODE solver must match input shape"

@@ -85,6 +85,12 @@ void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
     int wgs = 256 * (NW == 4 ? 1 : 1);
     const int grid = grid_arg > 0 ? grid_arg : std::min(ntile, wgs);
     TailArgs ta{wt, A, Z, b1 + 3 * HHD, b2, gate, h, A2, nshift, nscale, N, M, K2, mod_stride, tpt, magic_of(tpt)};
+#ifdef TAIL_STAMPS
+    unsigned long long *dbg;
+    CK(hipMalloc(&dbg, (size_t)grid * NW * 10 * 8));
+    CK(hipMemset(dbg, 0, (size_t)grid * NW * 10 * 8));
+    ta.dbg = dbg;
+#endif
     printf("  lds %zu bytes, grid %d x %d threads, %d tiles of %d tokens, stream %.2f MB\n", lds, grid, NW * 64, ntile, C::TT, C::stream_bytes(M) / 1e6);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, 0, ta);
     CK(hipDeviceSynchronize());
@@ -143,6 +149,20 @@ void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
            rows.size(), worst_h, rms_upd, worst_h / rms_upd, worst_a, a_flips, a_total, pad_dirty);
     printf("  %s\n", (worst_h / rms_upd < 5e-3 && worst_a < 1.2e-2 && pad_dirty == 0) ? "RESULT OK" : "RESULT WRONG");
 
+#ifdef TAIL_STAMPS
+    {
+        std::vector<unsigned long long> hd((size_t)grid * NW * 10);
+        CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+        const char *nm[10] = {"vmcnt", "barrier", "issue", "O-step", "U-step", "D-step", "loads", "epilogue", "total", "other"};
+        for (int wg : {0, 100, grid - 1})
+            for (int w : {0, NW - 1}) {
+                const unsigned long long *d = &hd[((size_t)wg * NW + w) * 10];
+                printf("  wg %3d wave %d:", wg, w);
+                for (int k = 0; k < 10; ++k) printf(" %s %.0fk", nm[k], d[k] / 1e3);
+                printf("\n");
+            }
+    }
+#endif
     hipEvent_t ev0, ev1;
     CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
     const double flop = 2.0 * N * ((double)D * M * 2 + (double)HHD * D);
