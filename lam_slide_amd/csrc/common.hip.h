@@ -113,6 +113,32 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return fmaf(-ax, h, relu);
 }
 
+// erf-GELU of TWO accumulator values, rounded to one packed bf16 pair, with the polynomial and the final fma on the packed-fp32 pipe
+// (v_pk_fma_f32: 6 instead of 12 FMAs per pair; 13 vector instructions per pair where two gelu_fast calls + a pack take 21).  Same
+// polynomial and operation order per element as gelu_fast: the same values.  ASM_MAX: max(x, 0) as one inline-asm v_max_f32 (see
+// lin1_gelu, k_lin1.hip.h): only for values the matrix pipe finished writing long ago - inline asm is invisible to the hazard recognizer.
+template <bool ASM_MAX>
+__device__ __forceinline__ unsigned gelu_pair_bf16(float x0, float x1) {
+    const f32x2 x = {x0, x1};
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    f32x2 q = f32x2{-0.0004733090754598379f, -0.0004733090754598379f};
+    q = __builtin_elementwise_fma(q, ax, f32x2{0.0070845563896000385f, 0.0070845563896000385f});
+    q = __builtin_elementwise_fma(q, ax, f32x2{-0.051827382296323776f, -0.051827382296323776f});
+    q = __builtin_elementwise_fma(q, ax, f32x2{-0.4599924385547638f, -0.4599924385547638f});
+    q = __builtin_elementwise_fma(q, ax, f32x2{-1.1507878303527832f, -1.1507878303527832f});
+    q = __builtin_elementwise_fma(q, ax, f32x2{-1.000037670135498f, -1.000037670135498f});
+    const f32x2 h = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    f32x2 relu;
+    if (ASM_MAX) {
+        asm("v_max_f32 %0, 0, %1" : "=v"(relu[0]) : "v"(x0));
+        asm("v_max_f32 %0, 0, %1" : "=v"(relu[1]) : "v"(x1));
+    } else {
+        relu = f32x2{__builtin_amdgcn_fmed3f(x0, 0.0f, __builtin_inff()), __builtin_amdgcn_fmed3f(x1, 0.0f, __builtin_inff())};
+    }
+    const f32x2 r = __builtin_elementwise_fma(-ax, h, relu);
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+
 // Streaming ("nt") stores: the line is written out without staying resident in L2.  The GEMM epilogues write 0.5-1.3 GB per
 // launch through the 4 MiB L2 of each XCD; with plain stores that evicted the operand tiles every round (linear1 fetched
 // 1.1 GB per launch for 0.25 GB of operands; with nt stores 0.32 GB).  Inline asm on purpose: when a branch selects between

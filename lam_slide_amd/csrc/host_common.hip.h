@@ -49,6 +49,7 @@ struct lsl_model {
     bool attention_linear = false;  // lsl_model_set_attention_mode: attention_linear (mmdit.py:58-72) instead of softmax attention
     int chunk = 0;
     int HHD, F1, K2, MODW;
+    bool tail = false;  // the back half of every sub-block runs k_tail (k_tail.hip.h): a property of the MODEL (lsl_model_create), never of the batch
     // hipGraph cache of lsl_sample: a call whose arguments (pointers, sizes, step table) repeat is captured once and replayed; the
     // small-batch configs are launch-bound (~700 launches of a few microseconds per sampling call)
     struct GraphEntry {
@@ -80,12 +81,15 @@ struct Workspace {
     u16 *a, *qkv, *z;
     float *kmax2;  // [4 * depth]: bound of |k|^2 per attention block (k_rope_scaled), then of |q|^2 without the softmax pre-multiplier (same order): k_attention_stream's softmax shift
     u16 *w2p;  // linear2 weights of every sub-block in the fragment order of k_linear2_ws (k_lin2_pack, once per call), or NULL
+    u16 *wtail;  // tail models: the weight stream of every sub-block (k_tail_pack, once per call); wtail_stride elements apart
+    size_t wtail_stride;
     size_t bytes;
 };
 
 int env_int(const char *name, int dflt);
 int tune_int(const char *name, int dflt);
 bool linear2_ws_shape_ok(int D, int K2);
+size_t tail_stream_bytes(const lsl_model *m);
 
 // Scratch layout for a pass over `bc` trajectories.
 Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
@@ -104,7 +108,7 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.rope_qk = (float4 *)take((size_t)4 * d.depth * ws.rope_qk_stride * sizeof(float4));
     ws.kmax2 = (float *)take((size_t)4 * d.depth * sizeof(float));
     ws.cond_emb = (float *)take(n * D * 4);
-    ws.h = (float *)take(n * D * 4);
+    ws.h = (float *)take(align_up(n, 256) * D * 4);  // (whole 256-row tiles: k_tail reads the rows of its last wave tiles without clamping)
     ws.yemb = (float *)take((size_t)bc * D * 4);
     ws.tfeat = (float *)take((size_t)bc * 256 * 4);
     ws.hid = (float *)take((size_t)bc * D * 4);
@@ -120,7 +124,9 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.a = (u16 *)take(n_pad * D * 2);
     ws.qkv = (u16 *)take(n_pad * 3 * m->HHD * 2);  // (padded like a / z: the token-stationary linear1 stores whole 256-token tiles)
     ws.z = (u16 *)take(n_pad * m->K2 * 2);
-    ws.w2p = linear2_ws_shape_ok((int)D, m->K2) ? (u16 *)take((size_t)2 * d.depth * D * m->K2 * 2) : nullptr;
+    ws.w2p = !m->tail && linear2_ws_shape_ok((int)D, m->K2) ? (u16 *)take((size_t)2 * d.depth * D * m->K2 * 2) : nullptr;
+    ws.wtail_stride = m->tail ? tail_stream_bytes(m) / 2 : 0;
+    ws.wtail = m->tail ? (u16 *)take((size_t)2 * d.depth * ws.wtail_stride * 2) : nullptr;
     ws.bytes = off;
     return ws;
 }

@@ -61,6 +61,11 @@ void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream
         for (int bi = 0; bi < 2 * m->d.depth; ++bi)
             hipLaunchKernelGGL(k_lin2_pack, dim3(128), dim3(256), 0, st, ws.w2p + (size_t)bi * per, (const u16 *)m->blocks[bi].w2, m->d.hidden, m->K2);
     }
+    if (ws.wtail) {  // tail models: the weight stream of every sub-block in the order k_tail consumes it
+        for (int bi = 0; bi < 2 * m->d.depth; ++bi)
+            hipLaunchKernelGGL(k_tail_pack, dim3(256), dim3(256), 0, st, ws.wtail + (size_t)bi * ws.wtail_stride, (const u16 *)m->blocks[bi].w1,
+                               (const u16 *)m->blocks[bi].w2, m->d.hidden, m->HHD, m->d.mlp_dim);
+    }
     hipLaunchKernelGGL(k_rope_table, dim3((L * half + 255) / 256), dim3(256), 0, st, ws.rope_l, L, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
     hipLaunchKernelGGL(k_rope_table, dim3((T * half + 255) / 256), dim3(256), 0, st, ws.rope_t, T, m->d.head_dim, m->d.head_dim_pad, m->d.theta);
     // the same tables with each attention block's query / key norm scales folded in (spatial blocks: L positions, temporal: T)
@@ -104,7 +109,10 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     const int pdiv = temporal ? L : 1, pmod = temporal ? T : L;
     auto magic_of = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };
     if ((unsigned long long)n * (unsigned)std::max(pdiv, pmod) >= (1ull << 32)) return fail(-3, "pass too large for the position arithmetic");
-    const bool lin1_ts = linear1_ts_ok(d.head_dim_pad, D, m->F1, m->HHD, n);
+    // tail models (and never the debug taps, which hand out the GELU'd mlp half of z): linear1 computes q | k | v only
+    const bool tail = m->tail && ws.wtail && !stop_before_linear2;
+    const int F1 = tail ? 3 * m->HHD : m->F1;
+    const bool lin1_ts = linear1_ts_ok(d.head_dim_pad, D, F1, m->HHD, n);
     const int npad = (n + 255) & ~255;
     const bool planes = !m->attention_linear && qkv_planes_ok(d.head_dim_pad, D, d.heads, temporal ? T : L, temporal != 0, lin1_ts);
     // head-major planes are addressed with 32-bit per-lane byte offsets over the whole q | k | v buffer (k_lin1.hip.h flush, k_attn.hip.h
@@ -112,19 +120,19 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     if (planes && (unsigned long long)npad * 3ull * (unsigned)m->HHD * 2ull >= (1ull << 32)) return fail(-3, "pass too large for the q/k/v plane offsets (%d tokens: at most %llu with this model)", n, (unsigned long long)((1ull << 32) / (6ull * (unsigned)m->HHD)) - 256);
     if (lin1_ts) {
         const Lin1Args la{(const u16 *)bw.w1, ws.a, bw.b1, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
-                          ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->F1, n, m->HHD, d.mlp_dim,
+                          ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, F1, n, m->HHD, d.mlp_dim,
                           pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, nullptr, 0, planes ? 1 : 0, npad};
         launch_linear1_ts(d.head_dim_pad, D, la, st);
     } else if (d.head_dim_pad == 32) {
         EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                          ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->HHD, d.mlp_dim,
                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 0};
-        launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st, m->HHD);
+        launch_gemm((const u16 *)bw.w1, ws.a, F1, n, D, e, st, m->HHD);
     } else {
         EpiLinear1<16> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                          ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->HHD, d.mlp_dim,
                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 0};
-        launch_gemm((const u16 *)bw.w1, ws.a, m->F1, n, D, e, st, m->HHD);
+        launch_gemm((const u16 *)bw.w1, ws.a, F1, n, D, e, st, m->HHD);
     }
     m->prof.end(0, st);
     static const int nt_mask = tune_int("LSL_NT", 3);
@@ -162,6 +170,19 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     }
     m->prof.begin(1, st);
     if ((unsigned long long)n * (unsigned)(T * L) >= (1ull << 32)) return fail(-3, "pass too large for the trajectory arithmetic");
+    if (tail) {  // up-projection -> GELU -> down-projection + out-projection + gated residual + the next sub-block's LayerNorm + modulate
+        if (h != ws.h) return fail(-3, "the tail kernel runs on the workspace's residual stream");
+        if ((unsigned long long)npad * (unsigned)(4 * D) >= (1ull << 32)) return fail(-3, "pass too large for the residual-stream offsets");
+        const bool next = bi + 1 < 2 * d.depth;
+        const float *nb = mods + (size_t)((bi + 1) / 2) * 6 * D + (((bi + 1) & 1) ? 3 * D : 0);  // next sub-block: shift, scale
+        const TailArgs ta{ws.wtail + (size_t)bi * ws.wtail_stride, ws.a, ws.z, bw.b1 + 3 * m->HHD, bw.b2, mbase + 2 * D, h, next ? ws.a : nullptr,
+                          nb, nb + D, n, d.mlp_dim, m->K2, mod_stride, T * L, magic_of(T * L)};
+        launch_tail(ta, st);
+        if (a_written) *a_written = next;
+        m->prof.end(1, st);
+        LSL_CHECK_LAUNCH("block (tail)");
+        return 0;
+    }
     const bool fuse = fuse_next && bi + 1 < 2 * d.depth && linear2_can_fuse_ln(D, n, m->K2);
     const float *nbase = mods + (size_t)((bi + 1) / 2) * 6 * D + (((bi + 1) & 1) ? 3 * D : 0);  // next sub-block: shift, scale
     bool on_ws = false;

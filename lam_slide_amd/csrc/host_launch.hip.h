@@ -283,6 +283,24 @@ bool launch_linear2_ws(int K2, const Lin2Args &a, int shared, hipStream_t st) {
     }
 }
 
+// The back half of a sub-block on the row-owning tail kernel (k_tail.hip.h): up-projection -> GELU in registers -> down-projection + attention
+// out-projection + gated residual + the next sub-block's LayerNorm.  Instances: hidden 256 with heads * head_dim_pad = 256 (the output tile
+// of a wave is hidden / 2 accumulator registers: 512 does not fit two waves per SIMD, and the one-wave-per-SIMD form measured slower than
+// what it replaces - profiles/r06_tail_experiments.txt).  Decided per MODEL in lsl_model_create; LSL_TAIL=0 (read in the product too: the
+// GPU suite compares the two decompositions) keeps linear1 (q | k | v | mlp) -> linear2 -> LayerNorm.
+bool tail_shape_ok(int D, int HHD, int M) {
+    static const int on = env_int("LSL_TAIL", 1);
+    return on && D == 256 && HHD == 256 && M % 32 == 0 && M >= 64 && TailCfg<256, 256>::lds_bytes(M) <= (size_t)163840;
+}
+size_t tail_stream_bytes(const lsl_model *m) { return TailCfg<256, 256>::stream_bytes(m->d.mlp_dim); }
+void launch_tail(const TailArgs &a, hipStream_t st) {
+    using C = TailCfg<256, 256>;
+    auto kern = k_tail<256, 256>;
+    LSL_ALLOW_LDS(kern, (size_t)163840);
+    const int nwt = (a.N + 31) / 32;  // wave tiles of 32 tokens: every workgroup gets at least one
+    hipLaunchKernelGGL(kern, dim3(std::min(nwt, device_cus())), dim3(512), C::lds_bytes(a.M), st, a);
+}
+
 // GEMM tiling (tuning knob LSL_GEMM; every variant sums k in the same order, so results are identical).
 //   (features x tokens, waves, BK x ring stages):
 //   5  256x256  8 waves 64x2, one tile per workgroup

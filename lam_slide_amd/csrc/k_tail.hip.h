@@ -35,7 +35,6 @@
 #include <type_traits>
 
 #include "common.hip.h"
-#include "k_lin1.hip.h"  // lin1_gelu
 
 struct TailArgs {
     const u16 *wt;       // packed weight stream of this sub-block (k_tail_pack)
@@ -44,41 +43,37 @@ struct TailArgs {
     const float *b1;     // [M]: linear1 bias, mlp section
     const float *b2;     // [D]
     const float *gate;   // mods + gate offset, row stride mod_stride (0: one row shared by every trajectory)
-    float *h;            // [N][D] fp32 residual stream, updated in place
+    float *h;            // [N rounded up to 256][D] fp32 residual stream, rows [0, N) updated in place
     u16 *a_next;         // [N rounded up to 256][D] bf16 or NULL (last sub-block: the head normalises itself); may alias A
     const float *ln_shift, *ln_scale;  // next sub-block's modulation rows (row stride mod_stride)
     int N, M, zw;
     int mod_stride, tpt;  // tokens per trajectory
     unsigned tpt_magic;   // floor(2^32 / tpt) + 1 (0 when tpt == 1)
-#ifdef TAIL_STAMPS
-    unsigned long long *dbg;  // tools/tail_harness.hip only: cycle sums per workgroup and wave
-#endif
 };
 
-template <int D, int HHD, int NW>
+template <int D, int HHD>
 struct TailCfg {
-    static_assert(D % 64 == 0 && D <= 512 && HHD % 64 == 0, "hidden sizes 128 .. 512");
+    static_assert(D % 64 == 0 && D <= 256 && HHD % 64 == 0, "hidden sizes 64 .. 256 (the output tile of a wave is D / 2 accumulator registers)");
+    static constexpr int NW = 8;            // waves per workgroup: two per SIMD, waves w and w + 4 share one
     static constexpr int NT = D / 32;       // output tiles of 32 features
     static constexpr int KS = D / 16;       // k-steps of the up-projection = B fragments a wave keeps
     static constexpr int KZ = HHD / 16;     // k-steps of the attention half
     static constexpr int CHF = D / 16;      // fragments per chunk
     static constexpr int CH = CHF * 1024;   // bytes per chunk
     static constexpr int CO = HHD / 32;     // chunks of the attention half
-    static constexpr int NS = NW == 8 ? 4 : 3;  // two chunks in flight, one (two with the skewed half) in use
+    static constexpr int NS = 6;            // ring slots = three PAIRS of chunks: the leading half's pair, the trailing half's older chunk, the pair in flight
     static constexpr int PPW = CHF / NW;    // DMA instructions per wave and chunk
     static_assert(CHF % NW == 0, "whole DMA instructions per wave");
     static constexpr int RING = NS * CH, STAGE = NW * 4096;
-    static constexpr int TT = NW * 32;      // tokens per tile
     static constexpr size_t lds_bytes(int M) { return (size_t)RING + STAGE + (size_t)M * 4; }
     static size_t stream_bytes(int M) { return (size_t)(CO + 2 * (M / 32)) * CH; }
 };
 
 // Weight stream of one sub-block.  16-byte piece i = lane (r = lane & 31, hf = lane >> 5) of fragment f of chunk c:
-//   c < CO                      Wo:  fragment f = 2 ft + s -> W2[32 ft + r][32 c + 16 s + 8 hf + 0..7]
-//   then e = c - CO: e = 0 U(0); odd e < 2 MB - 1: U((e + 1) / 2); even e: D(e / 2 - 1); e = 2 MB - 1: D(MB - 1)
-//   U(j): fragment ks -> W1[3 HHD + 32 j + r][16 ks + 8 hf + 0..7]
-//   D(j): fragment f = 2 ft + s -> W2[32 ft + r][HHD + 32 j + phi(s, hf, 0..7)],  phi = 16 s + 8 (i >> 2) + 4 hf + (i & 3):
-//         the mlp feature whose GELU sits in accumulator register 8 s + i of a lane of half hf (common.hip.h: mfma32 C/D map)
+//   c < CO         Wo:   fragment f = 2 ft + s -> W2[32 ft + r][32 c + 16 s + 8 hf + 0..7]
+//   c = CO + 2 j   U(j): fragment ks -> W1[3 HHD + 32 j + r][16 ks + 8 hf + 0..7]
+//   c = CO + 2 j+1 D(j): fragment f = 2 ft + s -> W2[32 ft + r][HHD + 32 j + phi(s, hf, 0..7)],  phi = 16 s + 8 (i >> 2) + 4 hf + (i & 3):
+//                  the mlp feature whose GELU sits in accumulator register 8 s + i of a lane of half hf (common.hip.h: mfma32 C/D map)
 __global__ void __launch_bounds__(256) k_tail_pack(u16 *out, const u16 *W1, const u16 *W2, int D, int HHD, int M) {
     const int CHF = D / 16, CO = HHD / 32, MB = M / 32, K2 = HHD + M;
     const long total = (long)(CO + 2 * MB) * CHF * 64;
@@ -91,13 +86,10 @@ __global__ void __launch_bounds__(256) k_tail_pack(u16 *out, const u16 *W1, cons
             const int ft = f >> 1, s = f & 1;
             v = *reinterpret_cast<const u32x4 *>(W2 + (size_t)(32 * ft + r) * K2 + 32 * c + 16 * s + 8 * hf);
         } else {
-            const int e = c - CO;
-            const bool up = e == 0 || ((e & 1) && e < 2 * MB - 1);
-            if (up) {
-                const int j = e == 0 ? 0 : (e + 1) >> 1;
+            const int e = c - CO, j = e >> 1;
+            if ((e & 1) == 0) {
                 v = *reinterpret_cast<const u32x4 *>(W1 + (size_t)(3 * HHD + 32 * j + r) * D + 16 * f + 8 * hf);
             } else {
-                const int j = e == 2 * MB - 1 ? MB - 1 : (e >> 1) - 1;
                 const int ft = f >> 1, s = f & 1;
                 const u16 *src = W2 + (size_t)(32 * ft + r) * K2 + HHD + 32 * j + 16 * s + 4 * hf;
                 const u32x2 lo = *reinterpret_cast<const u32x2 *>(src), hi = *reinterpret_cast<const u32x2 *>(src + 8);
@@ -108,31 +100,22 @@ __global__ void __launch_bounds__(256) k_tail_pack(u16 *out, const u16 *W1, cons
     }
 }
 
-#ifndef TAIL_PD
-#define TAIL_PD 0  // A fragments requested this many MFMAs ahead (0: 2 at two waves per SIMD, 6 at one)
-#endif
-#ifndef TAIL_SKEW
-#define TAIL_SKEW 1  // waves 4-7 of an 8-wave workgroup run one chunk behind waves 0-3 (their SIMD partners)
-#endif
-
-template <int D, int HHD, int NW>
-__global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
-    using C = TailCfg<D, HHD, NW>;
-    constexpr int NT = C::NT, KS = C::KS, KZ = C::KZ, CHF = C::CHF, CH = C::CH, CO = C::CO, NS = C::NS, PPW = C::PPW;
-    constexpr int PD = TAIL_PD ? TAIL_PD : (NW == 8 ? 2 : 6);
-    constexpr bool SKEW = TAIL_SKEW && NW == 8;
+template <int D, int HHD>
+__global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
+    using C = TailCfg<D, HHD>;
+    constexpr int NW = C::NW, NT = C::NT, KS = C::KS, KZ = C::KZ, CHF = C::CHF, CH = C::CH, CO = C::CO, NS = C::NS, PPW = C::PPW;
+    constexpr int PD = 2;  // A fragments requested this many MFMAs ahead
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hf = lane >> 5;
     char *const stage = smem + C::RING + wave * 4096;
     float *const b1_lds = reinterpret_cast<float *>(smem + C::RING + C::STAGE);
 
     // Work = wave tiles of 32 tokens, cut evenly over the workgroups; a workgroup walks its range in rounds of NW wave tiles (one per wave).  In
     // a last, partial round the waves without a tile only keep the ring going: with one active wave per SIMD the round is bound by half the
     // MFMA work, so 2.5 rounds of work take about 2.6 round times, not 3.
-    const int MB = g.M >> 5, NCH = CO + 2 * MB;
+    const int MB = g.M >> 5, NPAIR = (CO + 2 * MB) >> 1;
     const int nwt = (g.N + 31) >> 5;
     const int w0 = (int)((long)nwt * blockIdx.x / gridDim.x), w1 = (int)((long)nwt * (blockIdx.x + 1) / gridDim.x);
     if (w0 >= w1) return;  // (uniform)
@@ -140,79 +123,70 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
 
     for (int i = tid * 4; i < g.M; i += NW * 64 * 4) *reinterpret_cast<float4 *>(b1_lds + i) = *reinterpret_cast<const float4 *>(g.b1 + i);
 
-    // ---- weight ring: the stream's chunk -> slot; wave w requests fragments PPW w .. PPW w + PPW - 1 of a chunk, one LDS-DMA instruction each
-    // (inline asm on purpose, k_lin1.hip.h: behind the builtin hipcc waits for the request in front of the next LDS access of any kind)
+    // Everything a phase needs per lane (row / chunk indices, staging addresses, row pointers, fragment bases) is derived from a lane id that
+    // is laundered INSIDE that phase: hipcc cannot hoist those values out of the round loop, where - with the output tile and the activations
+    // resident - they would live in scratch, and a scratch reload inside the chunk loop is a vector-memory operation whose wait also waits
+    // for the ring requests just issued.
+    auto fresh_lane = [&]() __attribute__((always_inline)) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    // ---- weight ring: the stream's chunk k -> slot k mod 6; wave w requests fragments PPW w .. PPW w + PPW - 1 of a chunk, one LDS-DMA
+    // instruction each (inline asm on purpose, k_lin1.hip.h: behind the builtin hipcc waits for the request in front of the next LDS access)
     const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))(smem);
-    const unsigned lane_src = lane * 16;
     const char *const w_base = reinterpret_cast<const char *>(g.wt) + (size_t)wave * PPW * 1024;
     auto issue_piece = [&](const char *src, unsigned dst, auto ic) __attribute__((always_inline)) {
         constexpr int I = decltype(ic)::value;
-        const unsigned ls = lane_src;
-        asm volatile("s_add_u32 m0, %2, 0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(ls), "s"(src), "s"(dst), "n"(1024 * (I & 3)) : "memory", "scc");
+        const unsigned ls = (unsigned)fresh_lane() * 16u;
+        asm volatile("s_add_u32 m0, %2, 0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(ls), "s"(src), "s"(dst), "n"(1024 * I) : "memory", "scc");
     };
-    int c_src = 0, slot_d = 0;  // next chunk of the stream to request (index in [0, NCH)), and its slot
-    auto issue = [&]() __attribute__((always_inline)) {
-        const char *src = w_base + (size_t)c_src * CH;
+    int p_src = 0, slot_d = 0;  // next PAIR of the stream to request (index in [0, NPAIR)), and its first slot (0, 2 or 4)
+    auto issue_pair = [&]() __attribute__((always_inline)) {
+        const char *src = w_base + (size_t)p_src * (2 * CH);
         const unsigned dst = lds0 + slot_d * CH + wave * PPW * 1024;
         issue_piece(src, dst, std::integral_constant<int, 0>());
         if constexpr (PPW > 1) issue_piece(src, dst, std::integral_constant<int, 1>());
-        if constexpr (PPW > 2) issue_piece(src, dst, std::integral_constant<int, 2>());
-        if constexpr (PPW > 3) issue_piece(src, dst, std::integral_constant<int, 3>());
-        if constexpr (PPW > 4) {
-            issue_piece(src + 4096, dst + 4096, std::integral_constant<int, 0>());
-            if constexpr (PPW > 5) issue_piece(src + 4096, dst + 4096, std::integral_constant<int, 1>());
-            if constexpr (PPW > 6) issue_piece(src + 4096, dst + 4096, std::integral_constant<int, 2>());
-            if constexpr (PPW > 7) issue_piece(src + 4096, dst + 4096, std::integral_constant<int, 3>());
-        }
-        c_src = c_src + 1 == NCH ? 0 : c_src + 1;
-        slot_d = slot_d + 1 == NS ? 0 : slot_d + 1;
+        issue_piece(src + CH, dst + CH, std::integral_constant<int, 0>());
+        if constexpr (PPW > 1) issue_piece(src + CH, dst + CH, std::integral_constant<int, 1>());
+        p_src = p_src + 1 == NPAIR ? 0 : p_src + 1;
+        slot_d = slot_d == NS - 2 ? 0 : slot_d + 2;
     };
+    static_assert(PPW <= 2, "D <= 256");
     int slot_c = 0;  // slot of the next chunk this wave computes
-    // Barrier b of the workgroup: chunk b has landed (requested two barriers ago; younger than it are only the requests of chunk b + 1 - extra
-    // younger operations make the counted wait conservative, never wrong); the leading waves (all waves without the skew) compute chunk b
-    // behind it, the skewed half chunk b - 1; nobody reads chunk b - 2 (b - 1 without the skew) any more, and chunk b + 2 is requested into
-    // its slot.  Every wave passes the same barriers and issues at each of them.
-#ifdef TAIL_STAMPS
-    unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto stamp = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned long long t;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-        return t;
-    };
-    unsigned long long st_t = stamp();
-    const unsigned long long st_begin = st_t;
-#define TAIL_ST(k) { const unsigned long long t_ = stamp(); st_sum[k] += t_ - st_t; st_t = t_; }
-#else
-#define TAIL_ST(k)
-#endif
-    auto step_head = [&]() __attribute__((always_inline)) {
-        TAIL_ST(9)
-        wait_vmcnt<PPW>();
-        TAIL_ST(0)
+    // Barrier p of the workgroup (one wait + one barrier per PAIR of chunks: at one per chunk the barrier's drain - every wave stops, requests
+    // and restarts its fragment reads at the same moment - left the matrix pipe idle for a third of a step, measured).  The pair (2p, 2p + 1)
+    // has landed: requested a whole pair ago (EXTRA = vector-memory operations the wave has issued since, which may stay in flight).  Behind it
+    // the LEADING half (waves 0-3) computes chunks 2p, 2p + 1, the TRAILING half (waves 4-7: the SIMD partners) 2p - 1, 2p: one chunk behind,
+    // so that one wave's GELU (vector pipe) always runs beside its partner's MFMA chain and the two down- / up-projection chains of a SIMD
+    // never coincide with two GELUs.  Nobody reads chunks <= 2p - 2 any more: the pair (2p + 2, 2p + 3) is requested into their slots.
+    auto pair_head = [&](auto extra_c) __attribute__((always_inline)) {
+        wait_vmcnt<decltype(extra_c)::value>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        TAIL_ST(1)
-        issue();
-        TAIL_ST(2)
+        issue_pair();
     };
-    auto next_slot = [&]() __attribute__((always_inline)) { slot_c = slot_c + 1 == NS ? 0 : slot_c + 1; };
+    auto next_slot = [&]() __attribute__((always_inline)) { slot_c = slot_c == NS - 1 ? 0 : slot_c + 1; };
     auto frag = [&](const char *sb, int f) __attribute__((always_inline)) { return as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + f * 1024)); };
 
-    issue();
-    issue();
+    std::integral_constant<int, 0> E0;
+#ifdef TAIL_STAGGER
+    {   // harness experiment: workgroups start in TAIL_STAGGER phase groups, TAIL_STAGGER_SLEEPS x ~4 us apart
+        const int ph = (blockIdx.x >> 3) % TAIL_STAGGER;
+        for (int k = 0; k < ph * TAIL_STAGGER_SLEEPS; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    issue_pair();
     __syncthreads();  // bias table
-    const bool lag = SKEW && wave >= 4;  // (uniform)
-    if (lag) step_head();  // the skewed half starts one barrier late ...
 
-    const int chunk = lane & 7, rowi = lane >> 3;
     const unsigned st0 = (unsigned)(size_t)(LDS_PTR(char))(stage);
+    const unsigned b1_base = (unsigned)(size_t)(LDS_PTR(char))(smem + C::RING + C::STAGE);  // (uniform)
     // rows of a [tokens][K] bf16 matrix as MFMA B fragments (k_lin1.hip.h load_x / finish_x): whole 128-byte lines per 8 lanes (8 rows per
     // instruction), then line by line through the wave's staging image into fragment order, in place: line j of every row holds the k-steps
     // 4 j .. 4 j + 3; chunk c of row t sits at t 128 + 16 (c ^ ((t >> 1) & 7)), conflict-free for both accesses
     auto load_rows = [&](auto &xreg, auto ks_c, const u16 *X, int n0, int stride) __attribute__((always_inline)) {
         constexpr int NK = decltype(ks_c)::value;
+        const int l = fresh_lane(), chunk = l & 7, rowi = l >> 3;
         const u16 *xr = X + (size_t)(n0 + rowi) * stride + 8 * chunk;
 #pragma unroll
         for (int j = 0; j < NK / 4; ++j)
@@ -221,6 +195,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
     };
     auto finish_rows = [&](auto &xreg, auto ks_c) __attribute__((always_inline)) {
         constexpr int NK = decltype(ks_c)::value;
+        const int l = fresh_lane(), chunk = l & 7, rowi = l >> 3, r = l & 31, hf = l >> 5;
         const unsigned xw = st0 + rowi * 128, xr0 = st0 + r * 128;
 #pragma unroll
         for (int j = 0; j < NK / 4; ++j) {
@@ -232,15 +207,23 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
                 xreg[4 * j + m] = as_bf16x8(*reinterpret_cast<const LDS_PTR(u32x4)>(xr0 + ((((2 * m + hf) ^ (r >> 1)) & 7) << 4)));
         }
     };
+    constexpr int NPF = NT < 4 ? NT : 4;  // feature tiles of h in flight per wave
+    auto load_h = [&](f32x4_t (&v)[4], unsigned hoff, int ft) __attribute__((always_inline)) {  // rows (lane >> 3) + 8 i, 128 bytes of feature tile ft
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4_t *>(reinterpret_cast<const char *>(g.h) + (size_t)(hoff + (unsigned)(8 * i * 4 * D + 128 * ft)));
+    };
 
-    for (int rd = 0; rd < rounds; ++rd) {
-        const int wt = w0 + rd * NW + wave;
+    // One round of a wave.  LAG = 0: the leading half, barrier in front of every even chunk of the stream; LAG = 1: the trailing half, barrier
+    // in front of every odd chunk.  (The stream of a tile has CO + 2 MB chunks, CO even: chunk parity is static below.)
+    auto round = [&](auto lag_c, int wt) __attribute__((always_inline)) {
+        constexpr int LAG = decltype(lag_c)::value;
         if (wt >= w1) {  // (uniform) no tile for this wave in the last round: pass the round's barriers, keep requesting
-            for (int c = 0; c < NCH; ++c) {
-                step_head();
+            for (int c = 0; c < NPAIR; ++c) {
+                pair_head(E0);
+                next_slot();
                 next_slot();
             }
-            continue;
+            return;
         }
         const int n_wave = wt * 32;
         f32x16 out[NT];
@@ -254,11 +237,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
             bf16x8 zreg[KZ];
             load_rows(zreg, std::integral_constant<int, KZ>(), g.Z, n_wave, g.zw);
             finish_rows(zreg, std::integral_constant<int, KZ>());
-            TAIL_ST(6)
 #pragma unroll
             for (int c = 0; c < CO; ++c) {
-                step_head();
-                const char *sb = smem + slot_c * CH + lane * 16;
+                if ((c & 1) == LAG) pair_head(E0);
+                const char *sb = smem + slot_c * CH + fresh_lane() * 16;
                 bf16x8 fr[PD];
 #pragma unroll
                 for (int f = 0; f < PD; ++f) fr[f] = frag(sb, f);
@@ -268,117 +250,84 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
                     if (f + PD < CHF) fr[f % PD] = frag(sb, f + PD);
                 }
                 next_slot();
-                TAIL_ST(3)
+                __builtin_amdgcn_sched_barrier(0);  // (one chunk's fragments and temporaries live at a time)
             }
         }
 
-        // ---- mlp: up-projection -> GELU in registers -> down-projection ----
+        // ---- mlp, block by block: up-projection -> GELU in registers -> down-projection ----
         bf16x8 areg[KS];
         load_rows(areg, std::integral_constant<int, KS>(), g.A, n_wave, D);
         finish_rows(areg, std::integral_constant<int, KS>());
-        TAIL_ST(6)
-        f32x16 up0, up1;
-        auto init_up = [&](f32x16 &a, int j) __attribute__((always_inline)) {
+        f32x4_t hv[NPF][4];
+        auto block = [&](int j, auto last_c) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(last_c)::value != 0;
+            // U(j): the chain of block j from its bias
+            if (LAG == 0) pair_head(E0);
+            f32x16 up;
+            {
+                unsigned ba = b1_base + 16u * (unsigned)(fresh_lane() >> 5) + 128u * (unsigned)j;
+                asm volatile("" : "+v"(ba));  // (one per-lane base + immediates; no strength-reduced running pointer)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const float4 b = *reinterpret_cast<const float4 *>(b1_lds + j * 32 + 8 * q4 + 4 * hf);
-                a[4 * q4] = b.x; a[4 * q4 + 1] = b.y; a[4 * q4 + 2] = b.z; a[4 * q4 + 3] = b.w;
-            }
-        };
-        // U step: the chain of block j into `uc`; GELU of `ue` (block j - 1) in 8 slices behind eighths of the chain -> gw (8 packed words =
-        // the two B fragments of D(j - 1))
-        auto step_up = [&](f32x16 &uc, const f32x16 &ue, u32x4 (&gw)[2], auto mfma_c, auto gelu_c) __attribute__((always_inline)) {
-            constexpr bool DO_MFMA = decltype(mfma_c)::value != 0, DO_GELU = decltype(gelu_c)::value != 0;
-            constexpr int MPS = KS / 8 > 0 ? KS / 8 : 1;
-            const char *sb = smem + slot_c * CH + lane * 16;
-            bf16x8 fr[PD];
-            if (DO_MFMA) {
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4_t b = *reinterpret_cast<const LDS_PTR(f32x4_t)>(ba + 32 * q4);
+                    up[4 * q4] = b[0]; up[4 * q4 + 1] = b[1]; up[4 * q4 + 2] = b[2]; up[4 * q4 + 3] = b[3];
+                }
+                const char *sb = smem + slot_c * CH + fresh_lane() * 16;
+                bf16x8 fr[PD];
 #pragma unroll
                 for (int f = 0; f < PD; ++f) fr[f] = frag(sb, f);
-            }
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (DO_MFMA) {
-#pragma unroll
-                    for (int m = 0; m < MPS; ++m) {
-                        const int ks = s * MPS + m;
-                        if (ks < KS) {
-                            uc = mfma32(fr[ks % PD], areg[ks], uc);
-                            if (ks + PD < KS) fr[ks % PD] = frag(sb, ks + PD);
-                        }
-                    }
+                for (int ks = 0; ks < KS; ++ks) {
+                    up = mfma32(fr[ks % PD], areg[ks], up);
+                    if (ks + PD < KS) fr[ks % PD] = frag(sb, ks + PD);
                 }
-                if (DO_GELU) {
-                    // (the chain that wrote `ue` ended a whole step ago when DO_MFMA; the builtin form is used when it has only just ended)
-                    const float g0 = DO_MFMA ? lin1_gelu(ue[2 * s]) : gelu_fast(ue[2 * s]);
-                    const float g1 = DO_MFMA ? lin1_gelu(ue[2 * s + 1]) : gelu_fast(ue[2 * s + 1]);
-                    gw[s >> 2][s & 3] = pack2(g0, g1);
+                next_slot();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // GELU(j): 16 values per lane, rounded to bf16 = the two B fragments of D(j) (accumulator registers 8 s .. 8 s + 7 are k-step s)
+            u32x4 gw[2];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) gw[s >> 2][s & 3] = gelu_pair_bf16<false>(up[2 * s], up[2 * s + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            // D(j).  In front of the tile's last one: the h rows of the first NPF feature tiles are requested, behind the registers of the
+            // activations (dead now), so that they arrive under the chain.  Rows beyond N are read (h is padded to whole 256-row tiles), never written.
+            if (LAST) {
+                const int l = fresh_lane();
+                const unsigned hoff0 = (unsigned)(n_wave + (l >> 3)) * (unsigned)(4 * D) + 16u * (l & 7);
+#pragma unroll
+                for (int k = 0; k < NPF; ++k) load_h(hv[k], hoff0, k);
+                if (LAG == 1) pair_head(std::integral_constant<int, 4 * NPF>());
+            } else if (LAG == 1) pair_head(E0);
+            {
+                const char *sb = smem + slot_c * CH + fresh_lane() * 16;
+                bf16x8 fr[PD];
+#pragma unroll
+                for (int f = 0; f < PD; ++f) fr[f] = frag(sb, f);
+#pragma unroll
+                for (int f = 0; f < CHF; ++f) {
+                    out[f >> 1] = mfma32(fr[f % PD], as_bf16x8(gw[f & 1]), out[f >> 1]);
+                    if (f + PD < CHF) fr[f % PD] = frag(sb, f + PD);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                next_slot();
             }
-            if (DO_MFMA) next_slot();
-            TAIL_ST(4)
+            __builtin_amdgcn_sched_barrier(0);
         };
-        auto step_down = [&](const u32x4 (&gw)[2]) __attribute__((always_inline)) {
-            const char *sb = smem + slot_c * CH + lane * 16;
-            bf16x8 fr[PD];
-#pragma unroll
-            for (int f = 0; f < PD; ++f) fr[f] = frag(sb, f);
-#pragma unroll
-            for (int f = 0; f < CHF; ++f) {
-                out[f >> 1] = mfma32(fr[f % PD], as_bf16x8(gw[f & 1]), out[f >> 1]);
-                if (f + PD < CHF) fr[f % PD] = frag(sb, f + PD);
-            }
-            next_slot();
-            TAIL_ST(5)
-        };
-        std::integral_constant<int, 0> I0;
-        std::integral_constant<int, 1> I1;
-        u32x4 gw[2];
-        step_head();
-        init_up(up0, 0);
-        step_up(up0, up1, gw, I1, I0);
-        for (int j = 1; j + 1 < MB; j += 2) {  // blocks j (odd, into up1) and j + 1 (even, into up0)
-            step_head();
-            init_up(up1, j);
-            step_up(up1, up0, gw, I1, I1);
-            step_head();
-            step_down(gw);
-            step_head();
-            init_up(up0, j + 1);
-            step_up(up0, up1, gw, I1, I1);
-            step_head();
-            step_down(gw);
-        }
-        if ((MB & 1) == 0) {  // MB even: the last block is odd
-            step_head();
-            init_up(up1, MB - 1);
-            step_up(up1, up0, gw, I1, I1);
-            step_head();
-            step_down(gw);
-            step_up(up0, up1, gw, I0, I1);
-        } else {
-            step_up(up1, up0, gw, I0, I1);
-        }
-        step_head();
-        step_down(gw);
+        for (int j = 0; j + 1 < MB; ++j) block(j, std::integral_constant<int, 0>());
+        block(MB - 1, std::integral_constant<int, 1>());
 
         // ---- epilogue: h += gate (out + b2); LayerNorm + modulate of the next sub-block ----
+        const int le = fresh_lane(), chunk = le & 7, rowi = le >> 3, r = le & 31, hf = le >> 5;
         const int n_r = min(n_wave + r, g.N - 1);
         const unsigned traj = g.tpt_magic ? __umulhi((unsigned)n_r, g.tpt_magic) : (unsigned)n_r;
         const size_t mo = (size_t)traj * g.mod_stride;
         const unsigned wr_row = st0 + rowi * 128 + (((chunk ^ rowi) & 7) << 4);  // row-wise access: rows rowi + 8 i (same swizzle: (row & 7) = rowi)
+        const unsigned hoff = (unsigned)(n_wave + rowi) * (unsigned)(4 * D) + 16u * chunk;  // (a pass's h stays below 4 GiB: host-checked)
         float sum = 0.0f;
 #pragma unroll
         for (int ft = 0; ft < NT; ++ft) {
-            float4 hv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = min(n_wave + rowi + 8 * i, g.N - 1);
-                hv[i] = *reinterpret_cast<const float4 *>(g.h + (size_t)n * D + 32 * ft + 4 * chunk);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<LDS_PTR(f32x4_t)>(wr_row + 1024 * i) = f32x4_t{hv[i].x, hv[i].y, hv[i].z, hv[i].w};
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<LDS_PTR(f32x4_t)>(wr_row + 1024 * i) = hv[ft % NPF][i];
+            if (ft + NPF < NT) load_h(hv[ft % NPF], hoff, ft + NPF);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4_t hq = *reinterpret_cast<const LDS_PTR(f32x4_t)>(st0 + r * 128 + ((((2 * q + hf) ^ r) & 7) << 4));
@@ -399,7 +348,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
             for (int i = 0; i < 4; ++i) {
                 const int n = n_wave + rowi + 8 * i;
                 const f32x4_t v = *reinterpret_cast<const LDS_PTR(f32x4_t)>(wr_row + 1024 * i);
-                if (n < g.N) *reinterpret_cast<f32x4_t *>(g.h + (size_t)n * D + 32 * ft + 4 * chunk) = v;
+                if (n < g.N) *reinterpret_cast<f32x4_t *>(reinterpret_cast<char *>(g.h) + (size_t)(hoff + (unsigned)(8 * i * 4 * D + 128 * ft))) = v;
             }
         }
         if (g.a_next) {  // (uniform)
@@ -438,17 +387,17 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tail(TailArgs g) {
                 }
             }
         }
-        TAIL_ST(7)
-    }
-    if (SKEW && !lag) {  // ... and the leading half passes one more at the end: the same number of barriers for every wave
-        wait_vmcnt<PPW>();
+    };
+
+    if (wave < 4) {  // (uniform)
+        for (int rd = 0; rd < rounds; ++rd) round(std::integral_constant<int, 0>(), w0 + rd * NW + wave);
+        // ... the leading half passes one more barrier at the end: the same number for every wave
+        wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+    } else {
+        // the trailing half starts one chunk late: its first barrier is the workgroup's barrier 0, behind which it computes chunk 0 only
+        pair_head(E0);
+        for (int rd = 0; rd < rounds; ++rd) round(std::integral_constant<int, 1>(), w0 + rd * NW + wave);
     }
     wait_vmcnt<0>();  // the ring's run-ahead requests must not land in LDS after the workgroup has gone
-#ifdef TAIL_STAMPS
-    if (lane == 0 && g.dbg) {
-        st_sum[8] = stamp() - st_begin;
-        for (int k = 0; k < 10; ++k) g.dbg[((size_t)blockIdx.x * NW + wave) * 10 + k] = st_sum[k];
-    }
-#endif
 }

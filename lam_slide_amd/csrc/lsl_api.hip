@@ -24,6 +24,7 @@
 #include "k_gemm.hip.h"
 #include "k_lin1.hip.h"
 #include "k_lin2.hip.h"
+#include "k_tail.hip.h"
 #include "k_small.hip.h"
 #include "k_resident.hip.h"
 #ifdef LSL_EXPERIMENTS  // measured-and-rejected GEMM structures, built only by tools/build_experiments.sh (never in the product library)
@@ -68,6 +69,7 @@ int lsl_model_create(const lsl_model_desc *desc, lsl_model **out) try {
     m->F1 = 3 * m->HHD + d.mlp_dim;
     m->K2 = m->HHD + d.mlp_dim;
     m->MODW = (6 * d.depth + 2) * d.hidden;
+    m->tail = tail_shape_ok(d.hidden, m->HHD, d.mlp_dim);
     *out = m;
     return 0;
 } catch (const std::bad_alloc &) {
@@ -481,8 +483,11 @@ int lsl_debug_block(lsl_model *m, int32_t bi, const float *h_in, float *h_out, c
     const Workspace ws = carve(m, (char *)workspace, B, T, L);
     run_tables(m, ws, T, L, st);
     const size_t bytes = (size_t)B * T * L * m->d.hidden * 4;
-    if (h_in != h_out) hipMemcpyAsync(h_out, h_in, bytes, hipMemcpyDeviceToDevice, st);
-    return run_block(m, ws, bi, h_out, mods, m->MODW, B, T, L, st);
+    // (on the workspace's residual stream, like an evaluation: its rows are padded to whole tiles)
+    hipMemcpyAsync(ws.h, h_in, bytes, hipMemcpyDeviceToDevice, st);
+    if (int rc = run_block(m, ws, bi, ws.h, mods, m->MODW, B, T, L, st)) return rc;
+    hipMemcpyAsync(h_out, ws.h, bytes, hipMemcpyDeviceToDevice, st);
+    return 0;
 } catch (const std::bad_alloc &) {
     return fail(-5, "out of host memory");
 } catch (...) {

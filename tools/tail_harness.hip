@@ -41,9 +41,10 @@ static float bf2f_host(u16 v) {
     return f;
 }
 
-template <int D, int HHD, int NW>
+template <int D, int HHD>
 void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
-    using C = TailCfg<D, HHD, NW>;
+    using C = TailCfg<D, HHD>;
+    constexpr int NW = C::NW;
     const int Npad = (N + 255) / 256 * 256, F1 = 3 * HHD + M, F1pad = (F1 + 255) / 256 * 256, K2 = HHD + M, Dpad = (D + 255) / 256 * 256;
     const int ntraj = (N + tpt - 1) / tpt, MODW = 14 * D, mod_stride = shared ? 0 : MODW;
     printf("case N=%d D=%d HHD=%d M=%d tokens/traj=%d shared_mods=%d waves/wg=%d  (chunk %d KiB, ring slots %d, DMA per wave+chunk %d)\n", N, D, HHD, M, tpt, shared, NW,
@@ -62,7 +63,7 @@ void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
     float *b1, *b2, *mods, *h;
     CK(hipMalloc(&W1, hW1.size() * 2)); CK(hipMalloc(&W2, hW2.size() * 2)); CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&A2, hA.size() * 2));
     CK(hipMalloc(&Z, hZ.size() * 2)); CK(hipMalloc(&wt, C::stream_bytes(M)));
-    CK(hipMalloc(&b1, hb1.size() * 4)); CK(hipMalloc(&b2, hb2.size() * 4)); CK(hipMalloc(&mods, hmods.size() * 4)); CK(hipMalloc(&h, hh.size() * 4));
+    CK(hipMalloc(&b1, hb1.size() * 4)); CK(hipMalloc(&b2, hb2.size() * 4)); CK(hipMalloc(&mods, hmods.size() * 4)); CK(hipMalloc(&h, (size_t)Npad * D * 4));
     CK(hipMemcpy(W1, hW1.data(), hW1.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(W2, hW2.data(), hW2.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
@@ -78,23 +79,20 @@ void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
 
     hipLaunchKernelGGL(k_tail_pack, dim3(256), dim3(256), 0, 0, wt, W1, W2, D, HHD, M);
     CK(hipDeviceSynchronize());
-    auto kern = k_tail<D, HHD, NW>;
-    const size_t lds = C::lds_bytes(M);
+    auto kern = k_tail<D, HHD>;
+    const size_t lds = C::lds_bytes(M) + (getenv("TAIL_LDS_PAD") ? atoi(getenv("TAIL_LDS_PAD")) : 0);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-    const int ntile = (N + C::TT - 1) / C::TT;
-    int wgs = 256 * (NW == 4 ? 1 : 1);
-    const int grid = grid_arg > 0 ? grid_arg : std::min(ntile, wgs);
+    const int ntile = (N + 255) / 256;
+    int wgs = 256;
+    const int grid = grid_arg > 0 ? grid_arg : std::min((N + 31) / 32, wgs);
     TailArgs ta{wt, A, Z, b1 + 3 * HHD, b2, gate, h, A2, nshift, nscale, N, M, K2, mod_stride, tpt, magic_of(tpt)};
-#ifdef TAIL_STAMPS
-    unsigned long long *dbg;
-    CK(hipMalloc(&dbg, (size_t)grid * NW * 10 * 8));
-    CK(hipMemset(dbg, 0, (size_t)grid * NW * 10 * 8));
-    ta.dbg = dbg;
-#endif
-    printf("  lds %zu bytes, grid %d x %d threads, %d tiles of %d tokens, stream %.2f MB\n", lds, grid, NW * 64, ntile, C::TT, C::stream_bytes(M) / 1e6);
+    printf("  lds %zu bytes, grid %d x %d threads, %d tiles of %d tokens, stream %.2f MB\n", lds, grid, NW * 64, ntile, 256, C::stream_bytes(M) / 1e6);
+    const int reps = getenv("TAIL_REPS") ? atoi(getenv("TAIL_REPS")) : 1;
+    for (int rep = 0; rep < reps; ++rep) {
+    CK(hipMemcpy(h, hh.data(), hh.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(A2, 0, hA.size() * 2));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, 0, ta);
     CK(hipDeviceSynchronize());
-    printf("  kernel ran\n"); fflush(stdout);
 
     std::vector<float> r1(hh.size());
     std::vector<u16> ra(hA.size());
@@ -106,6 +104,7 @@ void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
     for (int k = 0; k < 16; ++k) rows.push_back(std::min(N - 1, 255 + k * 7));
     for (int k = 0; k < 8; ++k) rows.push_back(std::max(0, N - 1 - k));
     double worst_h = 0, worst_a = 0, rms_upd = 0, cnt = 0;
+    int n_bad = 0;
     size_t a_flips = 0, a_total = 0;
     for (int n : rows) {
         const size_t mo = (size_t)(shared ? 0 : n / tpt) * MODW;
@@ -127,6 +126,7 @@ void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
             rms_upd += upd * upd;
             cnt += 1;
             worst_h = std::max(worst_h, fabs(hn[f] - (double)r1[(size_t)n * D + f]));
+            if (fabs(hn[f] - (double)r1[(size_t)n * D + f]) > 5e-3 && n_bad++ < 12) printf("    bad h: n=%d (wave tile %d, row %d) f=%d got %.5f want %.5f start %.5f\n", n, n / 32, n % 32, f, r1[(size_t)n * D + f], hn[f], hh[(size_t)n * D + f]);
         }
         mean /= D;
         double var = 0;
@@ -148,21 +148,8 @@ void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
     printf("  rows checked %zu: max |h' - ref| = %.3e (rms of the update %.3e -> %.2e relative), a_next worst rel %.3e, beyond one bf16 ulp: %zu of %zu, dirty pad elements %zu\n",
            rows.size(), worst_h, rms_upd, worst_h / rms_upd, worst_a, a_flips, a_total, pad_dirty);
     printf("  %s\n", (worst_h / rms_upd < 5e-3 && worst_a < 1.2e-2 && pad_dirty == 0) ? "RESULT OK" : "RESULT WRONG");
-
-#ifdef TAIL_STAMPS
-    {
-        std::vector<unsigned long long> hd((size_t)grid * NW * 10);
-        CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
-        const char *nm[10] = {"vmcnt", "barrier", "issue", "O-step", "U-step", "D-step", "loads", "epilogue", "total", "other"};
-        for (int wg : {0, 100, grid - 1})
-            for (int w : {0, NW - 1}) {
-                const unsigned long long *d = &hd[((size_t)wg * NW + w) * 10];
-                printf("  wg %3d wave %d:", wg, w);
-                for (int k = 0; k < 10; ++k) printf(" %s %.0fk", nm[k], d[k] / 1e3);
-                printf("\n");
-            }
     }
-#endif
+
     hipEvent_t ev0, ev1;
     CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
     const double flop = 2.0 * N * ((double)D * M * 2 + (double)HHD * D);
@@ -181,12 +168,8 @@ int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 163840, D = argc > 2 ? atoi(argv[2]) : 256, M = argc > 3 ? atoi(argv[3]) : 1024;
     const int tpt = argc > 4 ? atoi(argv[4]) : 160, shared = argc > 5 ? atoi(argv[5]) : 0, iters = argc > 6 ? atoi(argv[6]) : 20;
     const int HHD = argc > 7 ? atoi(argv[7]) : D, grid = argc > 8 ? atoi(argv[8]) : 0;
-    if (D == 256 && HHD == 256) run_case<256, 256, 8>(N, M, tpt, shared, iters, grid);
-    else if (D == 128 && HHD == 128) run_case<128, 128, 8>(N, M, tpt, shared, iters, grid);
-#ifdef TAIL_BIG
-    else if (D == 512 && HHD == 512) run_case<512, 512, 4>(N, M, tpt, shared, iters, grid);
-    else if (D == 384 && HHD == 512) run_case<384, 512, 4>(N, M, tpt, shared, iters, grid);
-#endif
+    if (D == 256 && HHD == 256) run_case<256, 256>(N, M, tpt, shared, iters, grid);
+    else if (D == 128 && HHD == 128) run_case<128, 128>(N, M, tpt, shared, iters, grid);
     else printf("unsupported shape\n");
     return 0;
 }
