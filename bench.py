@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--chunk", type=int, default=0, help="trajectories per pass inside the library (0 = default)")
     ap.add_argument("--updates", type=int, default=0, help="profiling only: state updates per sampling call instead of the workload's (the line is marked "
                                                            "config.reduced_updates; never a headline number).  PMC passes of the 1000-step peptide call need it")
+    ap.add_argument("--tail", default="auto", choices=("auto", "on", "off"),
+                    help="sub-block decomposition of the model handle (lam_slide_amd.LatentSIV3.set_tail): auto = the tail form for the NBA family "
+                         "at >= 131 072 tokens per GPU (where it is faster), the default form elsewhere")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch and stage-1 legs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event passes (rocprofv3 runs: every launch of the trace then belongs to a warm-up or timed sampling call)")
@@ -229,11 +232,12 @@ def run_rank(args) -> int:
     n_evals = (skw["num_steps"] - 1) if method == "ODE" else skw["num_steps"]
     g = torch.Generator().manual_seed(1 + rank)
 
+    from lam_slide_amd import sample_sharded  # (pure torch.distributed logic: importable without the HIP library)
     if stub:
         dev = torch.device("cpu")
         init = torch.randn(B, 4, 4, kw["in_dim"], generator=g)
 
-        def sample_call():
+        def sample_call(first_traj=0):
             return init * 0.5
 
         def sync():
@@ -250,6 +254,10 @@ def run_rank(args) -> int:
         net.to(dev)
         if args.chunk:
             net.set_chunk(args.chunk)
+        # the caller's choice of decomposition, made per MODEL OBJECT (never per call): large NBA batches take the tail form
+        tail_on = args.tail == "on" or (args.tail == "auto" and args.workload == "nba" and B * T * L >= 131072)
+        if tail_on or args.tail == "off":
+            net.set_tail(tail_on)
         tr = CreateTransport("GVP", "data")()
         lat = torch.randn(B, T, L, kw["in_dim"], generator=g).to(dev)
         init = torch.randn(B, T, L, kw["in_dim"], generator=g).to(dev)
@@ -259,29 +267,38 @@ def run_rank(args) -> int:
         if y is not None:
             mk["y"] = y
         sampler = Sampler(tr, fused=True, seed=1234)
-        sampler.elem_offset = rank * B * T * L * kw["in_dim"]
         fn = sampler.get_sample_fn(method, skw)
         net.ensure_packed(dev)
         lib = _lib.load()
 
-        def sample_call():
+        def sample_call(first_traj=rank * B):
+            # (device noise, if the sampler draws any: the slice of the unsharded stream that belongs to this rank's trajectories)
+            sampler.elem_offset = first_traj * T * L * kw["in_dim"]
             return fn(init, net.forward, **mk)[-1]
 
         def sync():
             torch.cuda.synchronize()
 
-    # the one collective of the path: the final latents of every rank's trajectories are gathered on rank 0 (RCCL over xGMI with backend
-    # "nccl"); no rank needs the others' results, so nothing is broadcast back
-    gather = [torch.empty_like(init) for _ in range(world)] if world > 1 and rank == 0 else None
-
-    def gather_final(final):
-        dist.gather(final.contiguous(), gather, dst=0)
+    # Sharding and the one collective of the path go through the package's documented entry point (INTEGRATION.md section 3,
+    # lam_slide_amd.sample_sharded: contiguous batch split, no data-path collective, ONE gather of the final latents onto rank 0 - RCCL
+    # over xGMI with backend "nccl"): the function the 2-rank gloo test covers is the one a scaling run times.  Weak scaling: the global
+    # batch is world x B trajectories and rank r owns [r B, (r + 1) B); its inputs were generated on its own device above, so the
+    # "global" tensor handed to sample_sharded only carries the batch shape (an expanded view, no memory).
+    global_shape = torch.empty(1, device=dev).expand(B * world, *init.shape[1:])
 
     def one_step():
-        final = sample_call()
-        if world > 1:
-            gather_final(final)
-        return final
+        box = {}
+
+        def shard_fn(local, lo):
+            assert local.shape[0] == B and lo == rank * B, (local.shape, lo, rank, B)
+            box["final"] = sample_call(lo)
+            return box["final"]
+
+        sample_sharded(shard_fn, global_shape, dst=0)  # rank 0 gets the [world * B, T, L, C] result, the others None
+        return box["final"]
+
+    def gather_final(final):  # the collective alone (timed outside the timed region): the same call with the sampling replaced by its result
+        sample_sharded(lambda local, lo: final, global_shape, dst=0)
 
     def fence():
         if world > 1:
@@ -341,7 +358,7 @@ def run_rank(args) -> int:
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "build": None if stub else lib.lsl_build_info().decode(), "dtype": "bf16", "dtype_detail": "bf16 MFMA operands (linear1, linear2, attention), fp32 accumulators / residual state / small GEMMs",
         "data": "stub (launcher test, not a measurement)" if stub else "synthetic (seeded random weights and latents)",
-        "config": {"workload": args.workload, "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
+        "config": {"workload": args.workload, "tail": bool(not stub and net.tail), "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
                    "mlp_ratio": kw["mlp_ratio"], "sampler": method, "state_updates": n_evals, "batch_per_gpu": B,
                    "global_batch": B * world, "parallelism": f"batch-shard x{world}, 1 gather to rank 0 per step",
                    # rank r draws the device noise of global elements [r * stride, (r + 1) * stride): the slice of the unsharded stream
@@ -368,8 +385,11 @@ def run_rank(args) -> int:
         torch.cuda.synchronize()
         tm, ln = C.c_double(), C.c_int32()
         _lib.check(lib.lsl_profile_read(net._handle, C.byref(tm), C.byref(ln)))
+        profiled_pass.name = lib.lsl_profile_kernel_name(net._handle).decode()
         lib.lsl_profile_enable(net._handle, -1, 0)
         return tm.value, ln.value
+
+    profiled_pass.name = ""
 
     if not resident and not args.no_roofline:
         total_ms.value, launches.value = profiled_pass(args.profile_kernel)
@@ -385,19 +405,20 @@ def run_rank(args) -> int:
     if resident:  # the whole call is (groups of) one kernel: its rate is the whole-path rate
         launches_total = 1
         args.profile_kernel = -2
-    hdp = 16 if D // kw["num_heads"] <= 16 else 32
-    lin1_ts = D in (128, 256, 384, 512) and (kw["num_heads"] * hdp) % 64 == 0 and M % 64 == 0
-    lin1_name = ("k_linear1_ts (token-stationary linear1 + bias/QK-norm/RoPE/GELU epilogue)" if lin1_ts
-                 else "k_gemm_glds<EpiLinear1> (linear1 + QK-norm/RoPE/GELU epilogue)")
-    K2 = kw["num_heads"] * hdp + M
-    lin2_ws = D % 128 == 0 and D <= 512 and K2 in (1536, 1280, 768, 384) and os.environ.get("LSL_LIN2_WS", "1") != "0"
-    lin2_name = ("k_linear2_ws (weight-stationary linear2 + gate/residual epilogue)" if lin2_ws
-                 else "k_gemm_glds<EpiLinear2> (linear2 + gate/residual epilogue)")
-    kinfo = {
-        0: (lin1_name, 2.0 * tok_total * D * (3 * D + M) * block_evals),
-        1: (lin2_name, 2.0 * tok_total * (D + M) * D * block_evals),
-        2: ("k_attention", 4.0 * tok_total * D * (L + T) / 2 * block_evals),
-    }
+    # Which kernel a profile class launched is reported by the LIBRARY (lsl_profile_kernel_name: its own dispatch, recorded while the
+    # class was bracketed), not re-derived here; the algorithmic FLOPs of a class follow from that name's decomposition.
+    def class_info(kid, name):
+        tailed = name.startswith("k_tail") or "(q | k | v)" in name
+        flops = {0: 2.0 * tok_total * D * (3 * D + (0 if tailed else M)),
+                 1: 2.0 * tok_total * ((2 * M + D) * D if tailed else (D + M) * D),
+                 2: 4.0 * tok_total * D * (L + T) / 2}.get(kid, 0.0) * block_evals
+        what = {0: "linear1 + bias / QK-norm / RoPE" + ("" if tailed else " / GELU") + " epilogue",
+                1: "mlp up-projection + GELU + linear2 + gated residual + next LayerNorm" if tailed else "linear2 + gate / residual epilogue",
+                2: "attention"}.get(kid, f"kernel class {kid}")
+        return f"{name} ({what})" if name else what, flops
+
+    prof_name = profiled_pass.name if not resident else ""
+    kinfo = {args.profile_kernel: class_info(args.profile_kernel, prof_name)}
     kname, kflops_total = kinfo.get(args.profile_kernel, (f"kernel class {args.profile_kernel}", 0.0))
     if resident:
         kname, kflops_total = "k_resident (all state updates of a trajectory in one workgroup)", float(f_eval) * n_evals * B
@@ -408,13 +429,24 @@ def run_rank(args) -> int:
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see profiles/): both operand and
     # output bytes scale with the tokens of a launch (weights are < 1 % of them), so the per-token figure is scaled to this run's
     # tokens per launch.  The newest profiles/r*_traffic.json of this workload is used.
-    def committed_traffic(key):
-        """HBM-side bytes per launch of kernel `key` from the newest committed PMC profile of this workload, scaled to this run's
-        tokens per launch; not measured in this run (PMC counters need rocprofv3): the source file is named beside the number."""
+    def committed_traffic(key, name):
+        """HBM-side bytes per launch of class `key` from the newest committed PMC profile of this workload in which that class ran the
+        kernel this run timed (`name` as the library reports it), scaled to this run's tokens per launch; not measured in this run (PMC
+        counters need rocprofv3): the source file is named beside the number.  Also the committed kernel trace's average duration of that
+        kernel, for `profile_agrees`.  -> (bytes, source, trace_avg_us, trace_tokens_per_launch)"""
+        fam = name.split("<")[0] if name else ""
         for tf, tj in traffic_files():
-            if key and key in tj:
-                return int(tj[key]["bytes"] / tj["tokens_per_launch"] * min(pass_size, B) * T * L), os.path.relpath(tf, ROOT)
-        return None, None
+            if key and key in tj and fam and tj[key].get("kernel", "").startswith(fam) and (("(q | k | v)" in name) == bool(tj.get("tail"))):
+                scale = min(pass_size, B) * T * L / tj["tokens_per_launch"]
+                return int(tj[key]["bytes"] * scale), os.path.relpath(tf, ROOT), tj[key].get("avg_us"), tj["tokens_per_launch"]
+        return None, None, None, None
+
+    def agrees(avg_ms_, trace_us, trace_tok):
+        """The HIP-event average of this run against the committed rocprofv3 trace's average for the same kernel (same tokens per launch
+        only): within 3 %?  None when no committed trace of this kernel at this launch size exists."""
+        if not trace_us or trace_tok != min(pass_size, B) * T * L or avg_ms_ <= 0:
+            return None
+        return bool(abs(avg_ms_ * 1e3 / trace_us - 1.0) <= 0.03)
 
     def traffic_files():
         """(path, content) of the committed PMC-derived traffic files of THIS workload - profiles/rNN_traffic.json (headline) and
@@ -431,13 +463,14 @@ def run_rank(args) -> int:
         return [(tf, tj) for _, _, tf, tj in found]
 
     how = "separate sampling call after the timed region, per-launch HIP events on the launch stream (one stream, nothing co-running)"
-    traffic, traffic_src = committed_traffic({0: "linear1", 1: "linear2"}.get(args.profile_kernel))
+    traffic, traffic_src, trace_us, trace_tok = committed_traffic({0: "linear1", 1: "linear2"}.get(args.profile_kernel), prof_name)
     step_ms = dt / args.steps * 1e3
     out["roofline"] = {
         "bound": "mfma", "kernel": kname, "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
         "frac": (achieved / PEAK_BF16_DENSE_TFLOPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
         "measured": how if not resident else "whole call (one kernel)",
         "launches_timed": launches.value, "launches_per_call": launches_total, "avg_launch_ms": avg_ms,
+        "profile_avg_launch_ms": trace_us * 1e-3 if trace_us else None, "profile_agrees": agrees(avg_ms, trace_us, trace_tok),
         "flops_per_launch": flops_per_launch, "trajectories_per_pass": pass_size,
         "kernel_time_share": avg_ms * launches_total / step_ms,
         "whole_path_tflops": value * f_eval * n_evals / 1e12,
@@ -473,9 +506,11 @@ def run_rank(args) -> int:
     if not resident and args.profile_kernel == 0 and not args.no_roofline:  # the second GEMM of the block beside it
         ms2, ln2 = profiled_pass(1)
         avg2 = ms2 / max(1, ln2)
-        fl2 = kinfo[1][1] / max(1, launches_total)
-        tr2, tr2_src = committed_traffic("linear2")
-        out["roofline2"] = {"bound": "mfma / hbm", "kernel": kinfo[1][0], "achieved": fl2 / (avg2 * 1e-3) / 1e12 if avg2 > 0 else None,
+        name2, flops2 = class_info(1, profiled_pass.name)
+        fl2 = flops2 / max(1, launches_total)
+        tr2, tr2_src, tr2_us, tr2_tok = committed_traffic("linear2", profiled_pass.name)
+        out["roofline2"] = {"bound": "mfma / hbm", "kernel": name2, "profile_avg_launch_ms": tr2_us * 1e-3 if tr2_us else None,
+                            "profile_agrees": agrees(avg2, tr2_us, tr2_tok), "achieved": fl2 / (avg2 * 1e-3) / 1e12 if avg2 > 0 else None,
                             "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": fl2 / (avg2 * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS if avg2 > 0 else None,
                             "traffic": tr2, "traffic_source": tr2_src, "measured": how, "launches_timed": ln2, "avg_launch_ms": avg2,
                             "flops_per_launch": fl2, "kernel_time_share": avg2 * launches_total / step_ms}

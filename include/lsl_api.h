@@ -34,8 +34,9 @@ extern "C" {
  *    lsl_sample_ex, lsl_debug_taps, lsl_build_info exist.
  * 3: lsl_rk_lincomb / lsl_rk_dense / lsl_rk_error_ratio exist (state arithmetic of the adaptive and fixed-grid Runge-Kutta samplers);
  *    no signature of version 2 changed.
- * 4: lsl_model_set_attention_mode exists (attention_linear, mmdit.py:58-72); nothing else changed. */
-#define LSL_VERSION 4
+ * 4: lsl_model_set_attention_mode exists (attention_linear, mmdit.py:58-72); nothing else changed.
+ * 5: lsl_model_set_tail, lsl_model_tail, lsl_profile_kernel_name exist; no signature of version 4 changed. */
+#define LSL_VERSION 5
 
 typedef struct lsl_model lsl_model;
 
@@ -148,6 +149,17 @@ int lsl_model_set_chunk(lsl_model *m, int32_t trajectories_per_pass);
  * calls (cached graphs are dropped).  Models in linear mode always take the general path (lsl_sampler_path == 0). */
 int lsl_model_set_attention_mode(lsl_model *m, int32_t mode);
 
+/* Decomposition of a ParallelMLPAttentionV2 sub-block (mmdit.py:240-249) behind the attention.  0 (default): linear1 computes q | k | v | mlp,
+ * linear2 and the next LayerNorm are kernels of their own.  1: linear1 computes q | k | v only and ONE row-owning kernel (k_tail) runs the mlp
+ * up-projection, GELU, linear2 over [attention | gelu(mlp)], the gated residual update and the next sub-block's LayerNorm + modulate: 7.5
+ * instead of 12.3 KB of HBM traffic per token and sub-block at hidden 256 / mlp 1024, faster from about 10^5 tokens per pass, slower below
+ * (a workgroup streams the whole weight image per 256 tokens).  The two forms are not bit-identical (other summation order in linear2 and in
+ * the row statistics; same error against the fp32 reference), so the choice belongs to the MODEL HANDLE - never to the batch: a trajectory's
+ * bits stay the same in any batch, shard or pass.  Returns -21 if the model has no instance (hidden 256 with heads * head_dim_pad = 256).
+ * Environment LSL_TAIL=1 / 0 sets the default of new handles / disables the form (A/B runs, tests). */
+int lsl_model_set_tail(lsl_model *m, int32_t on);
+int32_t lsl_model_tail(const lsl_model *m); /* 1 if the handle runs the tail form */
+
 /* Trajectories the library processes per pass for a call of this size (<= B). */
 int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L);
 
@@ -218,6 +230,9 @@ int lsl_debug_mods(lsl_model *m, const float *t, const float *y, int32_t B, floa
  * 4 output head + state update, 5 input embedding, 6 modulation tables; -1 disables.
  * lsl_profile_read synchronises on the recorded events and returns their summed duration. */
 int lsl_profile_enable(lsl_model *m, int32_t kernel, int32_t max_launches);
+/* Name of the kernel the profiled class launched in the passes since lsl_profile_enable ("" if none): the label of a timing comes from the
+ * library's own dispatch, not from a copy of its rule. */
+const char *lsl_profile_kernel_name(const lsl_model *m);
 int lsl_profile_read(lsl_model *m, double *total_ms, int32_t *launches);
 
 /* ------------------------------------------------------------------------------------------------

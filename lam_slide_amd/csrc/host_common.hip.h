@@ -33,10 +33,19 @@ struct Profiler {
     void end(int k, hipStream_t st) {
         if (k == kernel && used < cap) hipEventRecord(ev[2 * used++ + 1], st);
     }
+    char name[96] = "";  // what the profiled class launched (lsl_profile_kernel_name)
+    void label(int k, const char *fmt, ...) {
+        if (k != kernel) return;
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(name, sizeof(name), fmt, ap);
+        va_end(ap);
+    }
     void clear() {
         for (auto e : ev) hipEventDestroy(e);
         ev.clear();
         kernel = -1; cap = used = 0;
+        name[0] = 0;
     }
 };
 
@@ -49,7 +58,7 @@ struct lsl_model {
     bool attention_linear = false;  // lsl_model_set_attention_mode: attention_linear (mmdit.py:58-72) instead of softmax attention
     int chunk = 0;
     int HHD, F1, K2, MODW;
-    bool tail = false;  // the back half of every sub-block runs k_tail (k_tail.hip.h): a property of the MODEL (lsl_model_create), never of the batch
+    bool tail = false;  // the back half of every sub-block runs k_tail (k_tail.hip.h): a property of the HANDLE (lsl_model_set_tail), never of the batch
     // hipGraph cache of lsl_sample: a call whose arguments (pointers, sizes, step table) repeat is captured once and replayed; the
     // small-batch configs are launch-bound (~700 launches of a few microseconds per sampling call)
     struct GraphEntry {

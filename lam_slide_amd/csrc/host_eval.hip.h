@@ -123,6 +123,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
                           ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, F1, n, m->HHD, d.mlp_dim,
                           pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, nullptr, 0, planes ? 1 : 0, npad};
         launch_linear1_ts(d.head_dim_pad, D, la, st);
+        m->prof.label(0, "k_linear1_ts<%d, %d>%s", d.head_dim_pad, D, tail ? " (q | k | v)" : "");
     } else if (d.head_dim_pad == 32) {
         EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                          ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->HHD, d.mlp_dim,
@@ -134,6 +135,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 0};
         launch_gemm((const u16 *)bw.w1, ws.a, F1, n, D, e, st, m->HHD);
     }
+    if (!lin1_ts) m->prof.label(0, "k_gemm_glds<EpiLinear1<%d>> (tiling %d)", d.head_dim_pad, gemm_variant<EpiLinear1<32>>(F1, D, n));
     m->prof.end(0, st);
     static const int nt_mask = tune_int("LSL_NT", 3);
     AttnArgs aa{};
@@ -162,6 +164,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
         else launch_attention_linear_t<16>(aa, st);
     } else if (d.head_dim_pad == 32) launch_attention_t<32>(aa, st);
     else launch_attention_t<16>(aa, st);
+    m->prof.label(2, "%s", m->attention_linear ? "k_attention_linear" : attention_stream_mode(aa.S, aa.H) || attention_grouped_ok(aa) ? "k_attention_stream" : "k_attention_rows / k_attention_tiny / k_attention");
     m->prof.end(2, st);
 
     if (stop_before_linear2) {  // (lsl_debug_taps)
@@ -178,6 +181,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
         const TailArgs ta{ws.wtail + (size_t)bi * ws.wtail_stride, ws.a, ws.z, bw.b1 + 3 * m->HHD, bw.b2, mbase + 2 * D, h, next ? ws.a : nullptr,
                           nb, nb + D, n, d.mlp_dim, m->K2, mod_stride, T * L, magic_of(T * L)};
         launch_tail(ta, st);
+        m->prof.label(1, "k_tail<%d, %d>", D, m->HHD);
         if (a_written) *a_written = next;
         m->prof.end(1, st);
         LSL_CHECK_LAUNCH("block (tail)");
@@ -189,10 +193,12 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     if (ws.w2p && !fuse && (unsigned long long)n * (unsigned)(4 * D) < (1ull << 32)) {  // (32-bit byte offsets into h)
         const Lin2Args l2{ws.w2p + (size_t)bi * D * m->K2, ws.z, bw.b2, mbase + 2 * D, h, D, n, mod_stride, T * L, magic_of(T * L), 0, 0, 0, nullptr};
         on_ws = launch_linear2_ws(m->K2, l2, mod_stride == 0, st);
+        if (on_ws) m->prof.label(1, "k_linear2_ws<%d>", m->K2);
     }
     if (!on_ws) {
         EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L, 0, magic_of(T * L), fuse ? ws.a : nullptr, nbase, nbase + D};
         launch_gemm((const u16 *)bw.w2, ws.z, D, n, m->K2, e2, st, 32, fuse);
+        m->prof.label(1, "k_gemm_glds<EpiLinear2> (tiling %d)", gemm_variant<EpiLinear2>(D, m->K2, n));
     }
     if (a_written) *a_written = fuse && !on_ws;
     m->prof.end(1, st);

@@ -286,11 +286,14 @@ bool launch_linear2_ws(int K2, const Lin2Args &a, int shared, hipStream_t st) {
 // The back half of a sub-block on the row-owning tail kernel (k_tail.hip.h): up-projection -> GELU in registers -> down-projection + attention
 // out-projection + gated residual + the next sub-block's LayerNorm.  Instances: hidden 256 with heads * head_dim_pad = 256 (the output tile
 // of a wave is hidden / 2 accumulator registers: 512 does not fit two waves per SIMD, and the one-wave-per-SIMD form measured slower than
-// what it replaces - profiles/r06_tail_experiments.txt).  Decided per MODEL in lsl_model_create; LSL_TAIL=0 (read in the product too: the
-// GPU suite compares the two decompositions) keeps linear1 (q | k | v | mlp) -> linear2 -> LayerNorm.
+// what it replaces - profiles/r06_tail_experiments.txt).  Chosen per HANDLE (lsl_model_set_tail; LSL_TAIL=1 makes it the default of new
+// handles, LSL_TAIL=0 disables it - both read in the product: A/B runs and the GPU suite compare the two decompositions), never per batch.
+int tail_env() {
+    static const int v = env_int("LSL_TAIL", -1);
+    return v;
+}
 bool tail_shape_ok(int D, int HHD, int M) {
-    static const int on = env_int("LSL_TAIL", 1);
-    return on && D == 256 && HHD == 256 && M % 32 == 0 && M >= 64 && TailCfg<256, 256>::lds_bytes(M) <= (size_t)163840;
+    return tail_env() != 0 && D == 256 && HHD == 256 && M % 32 == 0 && M >= 64 && TailCfg<256, 256>::lds_bytes(M) <= (size_t)163840;
 }
 size_t tail_stream_bytes(const lsl_model *m) { return TailCfg<256, 256>::stream_bytes(m->d.mlp_dim); }
 void launch_tail(const TailArgs &a, hipStream_t st) {

@@ -69,7 +69,7 @@ int lsl_model_create(const lsl_model_desc *desc, lsl_model **out) try {
     m->F1 = 3 * m->HHD + d.mlp_dim;
     m->K2 = m->HHD + d.mlp_dim;
     m->MODW = (6 * d.depth + 2) * d.hidden;
-    m->tail = tail_shape_ok(d.hidden, m->HHD, d.mlp_dim);
+    m->tail = tail_env() == 1 && tail_shape_ok(d.hidden, m->HHD, d.mlp_dim);
     *out = m;
     return 0;
 } catch (const std::bad_alloc &) {
@@ -173,6 +173,21 @@ int lsl_model_set_attention_mode(lsl_model *m, int32_t mode) try {
 } catch (...) {
     return fail(-11, "unexpected C++ exception");
 }
+
+int lsl_model_set_tail(lsl_model *m, int32_t on) try {
+    if (!m || (on != 0 && on != 1)) return fail(-1, "tail must be 0 or 1");
+    if (on && !tail_shape_ok(m->d.hidden, m->HHD, m->d.mlp_dim))
+        return fail(-21, "no tail kernel for this model (hidden 256 with heads * head_dim_pad = 256, mlp_dim a multiple of 32; LSL_TAIL=0 disables it)");
+    if (m->tail != (on == 1)) drop_graphs(m);
+    m->tail = on == 1;
+    return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
+}
+int32_t lsl_model_tail(const lsl_model *m) { return m && m->tail ? 1 : 0; }
+const char *lsl_profile_kernel_name(const lsl_model *m) { return m ? m->prof.name : ""; }
 
 int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L) {
     if (!m || B <= 0 || T <= 0 || L <= 0) return 0;

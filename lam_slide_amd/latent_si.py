@@ -127,6 +127,7 @@ class LatentSIV3(nn.Module):
         self._workspaces: "OrderedDict[tuple, Tensor]" = OrderedDict()
         self._pinned: "OrderedDict[tuple, Tensor]" = OrderedDict()
         self._chunk = 0
+        self._tail = None  # None: the library's default (LSL_TAIL); True / False: set_tail
         self.last_path = None  # "hip" after a forward, for tests that must prove the native path ran
 
     # ---- initialisation recipe of the reference (latent_si_v31.py:123-156) ----------------------------
@@ -177,9 +178,25 @@ class LatentSIV3(nn.Module):
             _lib.check(lib.lsl_model_set_weights(self._handle, C.byref(self._packed.c_weights)))
             if self._chunk:
                 lib.lsl_model_set_chunk(self._handle, self._chunk)
+            if self._tail is not None:
+                _lib.check(lib.lsl_model_set_tail(self._handle, int(self._tail)))
             if self.attention_mode != "scaled_dot_product":
                 _lib.check(lib.lsl_model_set_attention_mode(self._handle, 1))
         return self._packed
+
+    def set_tail(self, on: bool):
+        """Decomposition of every sub-block behind the attention (include/lsl_api.h, ``lsl_model_set_tail``): ``True`` = linear1 computes
+        q | k | v only and one row-owning kernel runs mlp up-projection -> GELU -> linear2 -> gated residual -> next LayerNorm (fewer HBM
+        bytes; faster from about 10^5 tokens per pass, slower below).  A property of the model object, never of the batch: a trajectory's
+        bits are the same in any batch.  Raises if the model has no instance (hidden 256, heads * head_dim_pad = 256)."""
+        self._tail = bool(on)
+        if self._handle:
+            _lib.check(_lib.load().lsl_model_set_tail(self._handle, int(self._tail)))
+
+    @property
+    def tail(self) -> bool:
+        """Whether the native handle runs the tail form (False before the weights are packed)."""
+        return bool(self._handle) and bool(_lib.load().lsl_model_tail(self._handle))
 
     def set_chunk(self, trajectories_per_pass: int):
         """Cache-residency knob: trajectories processed per pass through the layers (0 = library default)."""

@@ -22,9 +22,10 @@ SQ_WAIT="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_IN
 SQ_INST="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 TCC="TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
 
-pmc_pass() {  # <out dir> <name> "<counters>" <program...>
+pmc_pass() {  # <out dir> <name> "<counters>" <program...>   (the exit status of every pass goes into $out/passes.txt -> the summary's head)
   local out=$1 name=$2 ctr=$3; shift 3
   rocprofv3 --pmc $ctr --output-format csv -d "$out/$name" -- "$@" > "$out/$name.log" 2>&1
+  echo "# pass $name rc $?" >> "$out/passes.txt"
 }
 bench_line() { grep "^{" "$1" | tail -n 1; }
 short_line() { python3 -c "
@@ -54,6 +55,7 @@ prof|profile)
   else
     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- "${one[@]}" > "$out/trace.log" 2>&1
   fi
+  echo "# pass trace rc $?" >> "$out/passes.txt"
   pmc_pass "$out" pmc_sq "$SQ_WAIT" "${one[@]}"
   pmc_pass "$out" pmc_sq2 "$SQ_INST" "${one[@]}"
   pmc_pass "$out" pmc_tcc "$TCC" "${one[@]}"
@@ -62,6 +64,7 @@ prof|profile)
   cd "$root"
   dirs=("$out/trace"); for d in pmc_sq pmc_sq2 pmc_tcc pmc_fetch pmc_write; do [ -d "$out/$d" ] && dirs+=("$out/$d"); done
   { echo "# tools/gpu.sh $cmd $tag $*   (kernel trace, then PMC passes in runs of their own; one step per PMC pass)"
+    cat "$out/passes.txt"
     echo "# bench line of the traced run:"; bench_line "$out/trace.log"
     python3 tools/pmc_summary.py "${dirs[@]}"; } > "gpurun_out/prof_$tag.summary.txt" 2>&1
   bench_line "$out/trace.log" > "gpurun_out/prof_$tag.bench.json"
@@ -116,11 +119,12 @@ ab)
 libab)
   cd "$root"
   args=$1; shift
-  cp lam_slide_amd/liblamslide_hip.so /tmp/_product.so
-  trap 'cp /tmp/_product.so "$root/lam_slide_amd/liblamslide_hip.so"' EXIT
+  keep=$(mktemp /tmp/_product.XXXXXX.so)  # (a path of this run's own: two concurrent runs must not share the backup)
+  cp lam_slide_amd/liblamslide_hip.so "$keep"
+  trap 'cp "$keep" "$root/lam_slide_amd/liblamslide_hip.so"; rm -f "$keep"' EXIT
   for round in 1 2; do
     for lib in "$@"; do
-      if [ "$lib" = product ]; then cp /tmp/_product.so lam_slide_amd/liblamslide_hip.so; else cp "$lib" lam_slide_amd/liblamslide_hip.so; fi
+      if [ "$lib" = product ]; then cp "$keep" lam_slide_amd/liblamslide_hip.so; else cp "$lib" lam_slide_amd/liblamslide_hip.so; fi
       python3 bench.py $args --no-cpu --no-extras --breakdown 2>&1 | tail -1 | short_line "$lib"
     done
   done

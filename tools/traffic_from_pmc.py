@@ -17,7 +17,7 @@ import sys
 
 CLASSES = [  # (class, regex on the kernel name)
     ("linear1", r"k_linear1_ts|k_gemm_glds<.*EpiLinear1"),
-    ("linear2", r"k_linear2_ws|k_gemm_glds<.*EpiLinear2"),
+    ("linear2", r"k_linear2_ws|k_gemm_glds<.*EpiLinear2|k_tail<"),  # (the back half of a sub-block: profile class 1 of lsl_api.h)
     ("attention", r"k_attention"),
     ("ln_modulate", r"k_ln_modulate"),
     ("head", r"k_head_step"),
@@ -86,6 +86,11 @@ def main():
     if not (a.workload and a.batch and a.tokens_per_traj and a.calls):
         ap.error("no bench line in the summary: give --workload --batch --tokens-per-traj --calls")
     stats, counters = parse(a.summary)
+    # tools/gpu.sh records the exit status of every rocprofv3 pass in the summary's head ("# pass <name> rc <code>"): a crashed FETCH_SIZE /
+    # WRITE_SIZE pass leaves an under-counted (or empty) counter table, which must not become a traffic file
+    failed = [ln.strip() for ln in open(a.summary) if re.match(r"# pass \S+ rc (?!0\b)", ln)]
+    if failed:
+        sys.exit("refusing " + a.summary + ": " + "; ".join(failed))
     kernels = {}
     for name, st in stats.items():
         c = counters.get(name, {})
@@ -100,6 +105,8 @@ def main():
             kernels[name]["note"] = f"trace calls {st['calls']} != {n_f} launches x {a.calls} sampling calls"
     out = {"note": __doc__.split("\n\n")[2].replace("\n", " "), "source": os.path.relpath(a.summary), "workload": a.workload, "batch": a.batch,
            "tokens_per_step": a.batch * a.tokens_per_traj, "kernels": kernels}
+    if bl and bl["config"].get("tail"):
+        out["tail"] = True  # the handle ran the tail decomposition (bench.py config.tail): class "linear2" is k_tail, "linear1" computes q | k | v only
     if a.updates:
         out["state_updates"] = a.updates
     if a.commit:
