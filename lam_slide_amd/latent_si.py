@@ -188,7 +188,7 @@ class LatentSIV3(nn.Module):
         """Decomposition of every sub-block behind the attention (include/lsl_api.h, ``lsl_model_set_tail``): ``True`` = linear1 computes
         q | k | v only and one row-owning kernel runs mlp up-projection -> GELU -> linear2 -> gated residual -> next LayerNorm (fewer HBM
         bytes; faster from about 10^5 tokens per pass, slower below).  A property of the model object, never of the batch: a trajectory's
-        bits are the same in any batch.  Raises if the model has no instance (hidden 256, heads * head_dim_pad = 256)."""
+        bits are the same in any batch.  Raises ValueError if the model has no instance (hidden 256, heads * head_dim_pad = 256)."""
         self._tail = bool(on)
         if self._handle:
             _lib.check(_lib.load().lsl_model_set_tail(self._handle, int(self._tail)))

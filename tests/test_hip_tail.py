@@ -60,7 +60,7 @@ def test_tail_is_refused_where_no_instance_exists(dev):
         from lam_slide_amd import LatentSIV3
         net = LatentSIV3(reset_parameters=False, **kw).to(dev)
         net.ensure_packed(dev)
-        with pytest.raises(RuntimeError, match="no tail kernel"):
+        with pytest.raises(ValueError, match="no tail kernel"):
             net.set_tail(True)
         assert not net.tail
 
@@ -80,7 +80,7 @@ def test_tail_block_updates_against_oracle_and_default_form(name, dev):
     D = sh.hidden_size
     mods = torch.cat([taps[f"l{i}.mod"].reshape(B, 6 * D) for i in range(sh.depth)] + [taps["final_mod"].reshape(B, 2 * D)], dim=1).to(dev).contiguous()
     lib = _lib.load()
-    ws = torch.empty(1 << 26, dtype=torch.uint8, device=dev)
+    ws = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
     h_prev = taps["h0"]
     for i in range(sh.depth):
         g1 = taps[f"l{i}.mod"].reshape(B, 6 * D)[:, 2 * D:3 * D][:, None, None, :]
@@ -97,7 +97,7 @@ def test_tail_block_updates_against_oracle_and_default_form(name, dev):
                 outs.append(o.cpu())
             want = hout - hin
             parity(f"tail.{name}.block{bi}.update", rel_l2(outs[0] - hin, want), 1e-2)
-            parity(f"tail.{name}.block{bi}.vs_default", rel_l2(outs[0] - hin, outs[1] - hin), 6e-3)
+            parity(f"tail.{name}.block{bi}.vs_default", rel_l2(outs[0] - hin, outs[1] - hin), 2e-5)
         h_prev = h_end
 
 
@@ -116,7 +116,7 @@ def test_tail_forward_against_oracle(name, dev):
     assert net_t.last_path == "hip"
     parity(f"tail.{name}.forward", rel_l2(got_t, want), 6e-4)
     parity(f"tail.{name}.forward.default_form", rel_l2(got_d, want), 6e-4)
-    parity(f"tail.{name}.forward.vs_default", rel_l2(got_t, got_d), 6e-4)
+    parity(f"tail.{name}.forward.vs_default", rel_l2(got_t, got_d), 3e-5)
 
 
 def test_tail_sampler_against_oracle_and_batch_independence(dev):
@@ -174,4 +174,4 @@ def test_tail_at_a_large_pass_matches_default_form_and_is_labelled(dev):
         lib.lsl_profile_enable(net._handle, -1, 0)
         assert ln.value == 2 and tm.value > 0
     assert names[0].startswith("k_tail<256, 256>") and names[1].startswith("k_linear2_ws<1280>"), names
-    parity("tail.large_pass.vs_default", rel_l2(outs[0].cpu(), outs[1].cpu()), 6e-4)
+    parity("tail.large_pass.vs_default", rel_l2(outs[0].cpu(), outs[1].cpu()), 2e-5)
