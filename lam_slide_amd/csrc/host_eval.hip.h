@@ -121,7 +121,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     if (lin1_ts) {
         const Lin1Args la{(const u16 *)bw.w1, ws.a, bw.b1, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                           ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, F1, n, m->HHD, d.mlp_dim,
-                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, nullptr, 0, planes ? 1 : 0, npad};
+                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, 0, planes ? 1 : 0, npad};
         launch_linear1_ts(d.head_dim_pad, D, la, st);
         m->prof.label(0, "k_linear1_ts<%d, %d>%s", d.head_dim_pad, D, tail ? " (q | k | v)" : "");
     } else if (d.head_dim_pad == 32) {
@@ -191,7 +191,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     const float *nbase = mods + (size_t)((bi + 1) / 2) * 6 * D + (((bi + 1) & 1) ? 3 * D : 0);  // next sub-block: shift, scale
     bool on_ws = false;
     if (ws.w2p && !fuse && (unsigned long long)n * (unsigned)(4 * D) < (1ull << 32)) {  // (32-bit byte offsets into h)
-        const Lin2Args l2{ws.w2p + (size_t)bi * D * m->K2, ws.z, bw.b2, mbase + 2 * D, h, D, n, mod_stride, T * L, magic_of(T * L), 0, 0, 0, nullptr};
+        const Lin2Args l2{ws.w2p + (size_t)bi * D * m->K2, ws.z, bw.b2, mbase + 2 * D, h, D, n, mod_stride, T * L, magic_of(T * L), 0, 0, 0};
         on_ws = launch_linear2_ws(m->K2, l2, mod_stride == 0, st);
         if (on_ws) m->prof.label(1, "k_linear2_ws<%d>", m->K2);
     }

@@ -4,6 +4,23 @@
 
 // ---- launch helpers -------------------------------------------------------------------------------
 
+// Rejected structures and A/B arms (ping-pong / drain GEMMs, tilings 6 / 8 / 13-18 / 23-26 / 29, the scalar output head, every LSL_* tuning knob)
+// live in tools/experiments/host_launch_experiments.hip.h, on the include path of tools/build_experiments.sh only; the product has empty hooks.
+#ifdef LSL_EXPERIMENTS
+constexpr bool lsl_experiments = true;
+template <int NE, int VEC>
+bool launch_head_experiment(float *, float *, const float *, const float *, const float *, int, const float *, const float *, int, int, int, int, float, float,
+                            float, const float *, unsigned long long, unsigned, unsigned long long, float *, float, const float *, float *, hipStream_t);
+template <class Epi>
+bool launch_gemm_experiment(int, const GemmArgs &, const Epi &, hipStream_t, bool);
+#else
+constexpr bool lsl_experiments = false;
+template <int NE, int VEC, class... A>
+bool launch_head_experiment(A...) { return false; }
+template <class Epi>
+bool launch_gemm_experiment(int, const GemmArgs &, const Epi &, hipStream_t, bool) { return false; }
+#endif
+
 int device_cus();
 int env_int(const char *name, int dflt);
 
@@ -47,17 +64,7 @@ void launch_head_t(float *x, float *out, const float *h, const float *shift, con
                    const float *bo, int n, int C, int tpt, int do_step, float ax, float am, float aw, const float *noise,
                    unsigned long long seed, unsigned step, unsigned long long eo, float *trace, float as, const float *saved, float *save_out,
                    hipStream_t st) {
-#ifdef LSL_EXPERIMENTS
-    static const int mfma = tune_int("LSL_HEAD_MFMA", 1);  // 0: the scalar-FMA kernel (A/B measurements)
-    if (!mfma) {
-        auto kern = k_head_step<NE, VEC>;
-        constexpr size_t lds = head_lds_bytes<NE>();
-        LSL_ALLOW_LDS(kern, lds);
-        hipLaunchKernelGGL(kern, dim3(std::min((n + HEAD_TOK - 1) / HEAD_TOK, 256)), dim3(256), lds, st, x, out, h, shift, scale, stride, Wo, bo, n,
-                           C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace, as, saved, save_out);
-        return;
-    }
-#endif
+    if (launch_head_experiment<NE, VEC>(x, out, h, shift, scale, stride, Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace, as, saved, save_out, st)) return;
     launch_head_mfma<NE, VEC>(x, out, h, shift, scale, stride, Wo, bo, n, C, tpt, do_step, ax, am, aw, noise, seed, step, eo, trace, as, saved, save_out, st);
 }
 
@@ -115,14 +122,7 @@ int env_int(const char *name, int dflt) {
 }
 // Kernel-selection / timing knobs (LSL_GEMM*, LSL_NT, LSL_STAGGER, LSL_PROBE, ...): read from the environment only in
 // -DLSL_EXPERIMENTS builds; the product library always runs its measured defaults.
-int tune_int(const char *name, int dflt) {
-#ifdef LSL_EXPERIMENTS
-    return env_int(name, dflt);
-#else
-    (void)name;
-    return dflt;
-#endif
-}
+int tune_int(const char *name, int dflt) { return lsl_experiments ? env_int(name, dflt) : dflt; }
 
 int device_cus() {  // of the current device (entry points switch to the stream's device first)
     static std::atomic<int> cache[64];
@@ -170,47 +170,10 @@ bool gemm_rows_walk(int F, int N) {
     return ntt >= grid;
 }
 
+
 #ifdef LSL_EXPERIMENTS
-template <int BK, int NS, int NB, class Epi>
-void launch_gemm_pp_t(const GemmArgs &g, const Epi &epi, hipStream_t st) {
-    auto kern = k_gemm_pp<BK, NS, NB, Epi>;
-    constexpr size_t lds = GemmPPCfg<BK, NS, Epi>::lds_bytes;
-    LSL_ALLOW_LDS(kern, lds);
-    const int tiles = ((g.N + 255) / 256) * ((g.F + 127) / 128);
-    int grid = device_cus();
-    grid -= grid % 8;
-    if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g, epi);
-}
-
-// epilogue of tile i inside the main loop of tile i+1 (k_gemm_drain.hip.h); false when the shape is outside what it covers
-template <class Epi>
-bool launch_gemm_drain(const GemmArgs &g, const Epi &epi, hipStream_t st) {
-    if (g.F % 256 != 0 || g.N % 128 != 0 || g.K % 64 != 0 || g.K / 64 < 2) return false;
-    auto kern = k_gemm_drain<Epi>;
-    constexpr size_t lds = GemmDrainCfg<Epi>::lds_bytes;
-    LSL_ALLOW_LDS(kern, lds);
-    const int tiles = (g.N / 128) * (g.F / 256);
-    int grid = device_cus();
-    grid -= grid % 8;
-    if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g, epi);
-    return true;
-}
-
-// ping-pong halves (k_gemm_pp.hip.h); false when the shape is outside what the schedule covers
-template <int BK, int NS, class Epi>
-bool launch_gemm_pp(const GemmArgs &g, const Epi &epi, hipStream_t st) {
-    if (g.K % BK != 0 || g.F % 32 != 0) return false;
-    const int E = g.K / BK - (NS - 1);  // intervals that carry epilogue pieces
-    if (E < 1 || E > 64) return false;
-    if (E <= 16) launch_gemm_pp_t<BK, NS, 1>(g, epi, st);
-    else if (E <= 32) launch_gemm_pp_t<BK, NS, 2>(g, epi, st);
-    else launch_gemm_pp_t<BK, NS, 4>(g, epi, st);
-    return true;
-}
-
-#endif  // LSL_EXPERIMENTS
+#include "host_launch_experiments.hip.h"  // (needs launch_gemm_glds / device_cus above)
+#endif
 
 // linear1 on the token-stationary kernel (k_lin1.hip.h): hidden sizes 128 / 256 / 384 / 512, sections (q | k | v | mlp) on multiples of 64
 // features.  Same bits as the tile kernels below (tools/lin1_harness.hip), so the choice between them may depend on the launch size.
@@ -369,23 +332,10 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
     Epi epi = epi_in;
     epi.probe = probe | ((nt >> (std::is_same<Epi, EpiLinear2>::value ? 1 : 0)) & 1 ? 32 : 0);
     const bool pp_ok = !std::is_same<Epi, EpiLinear2>::value ? hhd % 32 == 0 : true;  // linear1 sections start on 32-feature tiles
-#ifdef LSL_EXPERIMENTS
-    if (variant == 30 && launch_gemm_drain(g, epi, st)) return;
-    if (variant == 20 && pp_ok && launch_gemm_pp<32, 4>(g, epi, st)) return;
-    if (variant == 21 && pp_ok && launch_gemm_pp<64, 2>(g, epi, st)) return;
-    if (variant == 22 && pp_ok && launch_gemm_pp<64, 3>(g, epi, st)) return;
-#endif
+    if (launch_gemm_experiment(variant, g, epi, st, pp_ok)) return;  // (rejected structures: -DLSL_EXPERIMENTS builds only)
     if (variant == 12 && K % 128 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, epi, st);  // 5 made persistent (staging in ring slot 1)
-#ifdef LSL_EXPERIMENTS
-    constexpr bool pieces_ok = true;
-#else
-    constexpr bool pieces_ok = std::is_same<Epi, EpiLinear2>::value;  // (linear1's piece epilogue exists in the experiments build only)
-#endif
-    if constexpr (pieces_ok) {
+    if constexpr (lsl_experiments || std::is_same<Epi, EpiLinear2>::value) {  // (linear1's piece epilogue exists in the experiments build only)
         if (variant == 7 && F % 32 == 0 && pp_ok && K % 128 == 0) return launch_gemm_glds<256, 256, 2, 4, 64, 2, true>(g, EpiPieces<Epi>(epi), st);  // persistent, 64-deep k-tiles, piece epilogue
-#ifdef LSL_EXPERIMENTS
-        if (variant == 8 && F % 32 == 0 && pp_ok) return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, EpiPieces<Epi>(epi), st);  // variant 6 with the piece epilogue
-#endif
     }
     switch (variant) {
         case 5: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);
@@ -394,22 +344,7 @@ void launch_gemm(const u16 *W, const u16 *X, int F, int N, int K, const Epi &epi
         case 28:  // 192 features x 128 tokens, 8 waves of 96 x 32, three 64-deep ring slots (linear2 of the 384-wide models)
             if constexpr (std::is_same<Epi, EpiLinear2>::value) return launch_gemm_glds<192, 128, 2, 4, 64, 3, false>(g, epi, st);
             else break;
-#ifdef LSL_EXPERIMENTS
-        case 26: if constexpr (std::is_same<Epi, EpiLinear2>::value) return launch_gemm_glds<192, 128, 2, 4, 64, 2, false>(g, epi, st); else break;  // 192 features x 128 tokens, 8 waves of 96 x 32 (F = 384: 2 x 125 tiles at 16 000 tokens)
-        case 29: if constexpr (std::is_same<Epi, EpiLinear2>::value) return launch_gemm_glds<192, 256, 2, 4, 64, 2, false>(g, epi, st); else break;  // 8 waves of 96 x 64: 2 x 63 tiles
-        case 23: return launch_gemm_glds<512, 128, 4, 2, 32, 3, false>(g, epi, st);  // whole residual rows per workgroup (F = 512): 120 KiB ring
-        case 24: return launch_gemm_glds<512, 128, 4, 2, 32, 2, false>(g, epi, st);
-        case 25: return launch_gemm_glds<512, 128, 4, 2, 32, 3, true>(g, EpiPieces<Epi>(epi), st);
-        case 16: return launch_gemm_glds<128, 256, 2, 4, 64, 2, false>(g, epi, st);  // 128 features x 256 tokens, 8 waves of 64 x 64
-        case 17: return launch_gemm_glds<128, 256, 2, 4, 32, 3, false>(g, epi, st);
-        case 18: return launch_gemm_glds<128, 256, 1, 8, 64, 2, false>(g, epi, st);  // 8 waves of 128 x 32
-        case 13: return launch_gemm_glds<256, 128, 2, 2, 32, 2, true>(g, epi, st);
-        case 14: return launch_gemm_glds<256, 128, 2, 2, 64, 2, true>(g, epi, st);  // 4 waves, one per SIMD, 64-deep k-tiles, one workgroup per CU
-#endif
         case 15: return launch_gemm_glds<256, 256, 4, 4, 64, 2, false>(g, epi, st);
-#ifdef LSL_EXPERIMENTS
-        case 6: return launch_gemm_glds<256, 256, 2, 4, 32, 3, true>(g, epi, st);
-#endif
         default: return launch_gemm_glds<256, 256, 2, 4, 64, 2, false>(g, epi, st);  // (K is a multiple of 64: hidden sizes are)
     }
 }

@@ -41,7 +41,6 @@ struct Lin1Args {
     unsigned div_magic, mod_magic;  // floor(2^32 / d) + 1 (0 when d == 1)
     float inv_hd, q_premul;
     int nt;                         // streaming stores
-    unsigned long long *dbg;        // timing-probe builds only (LIN1_PROBE & 128): per workgroup and wave, 4 cycle sums; else unused
     int wpt;                        // 0: the (tile, block) sequence is cut evenly over the grid; > 0: wpt workgroups per token tile, grid = wpt x tiles
     int planes;                     // 1 = q / k / v leave as head-major planes qkv[section][head][npad tokens][HDP] (a (sequence, head)'s rows are
                                     // then contiguous: k_attention_stream's spatial units), 0 = token-major rows qkv[token][3 HHD]
@@ -78,26 +77,8 @@ struct Lin1Cfg {
 
 enum { LIN1_QK = 0, LIN1_V = 1, LIN1_MLP = 2 };
 
-// Timing probes for tools/lin1_harness.hip ONLY (compile-time; results wrong when set; the library is built without the macro):
-// 1 no epilogue arithmetic, 2 no MFMAs / fragment reads, 4 no output stores, 8 no weight DMA, 16 no per-block wait + barrier,
-// 64 no fragment reads inside the MFMA chain, 128 cycle stamps per step phase into Lin1Args::dbg
-#ifndef LIN1_PROBE
-#define LIN1_PROBE 0
-#endif
-#ifndef LIN1_ATTN_PROBE
-#define LIN1_ATTN_PROBE 0  // harness only: adds the per-head work of a fused spatial attention to the step (see fused())
-#endif
-#ifndef LIN1_PRIO
-#define LIN1_PRIO 0
-#endif
 #ifndef LIN1_XLOAD
 #define LIN1_XLOAD 1  // 1: activations loaded as whole cache lines and transposed through the staging image; 0: fragment-shaped loads
-#endif
-#ifndef LIN1_DRAIN_NT
-#define LIN1_DRAIN_NT 1
-#endif
-#ifndef LIN1_ALL_PLAIN
-#define LIN1_ALL_PLAIN 0
 #endif
 #ifndef LIN1_PD
 #define LIN1_PD 3  // A fragments requested this many k-steps ahead of their MFMA
@@ -153,8 +134,6 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     // form of this kernel (one wave per SIMD, 64 tokens and the whole 512-register file per wave, each weight fragment read once for two
     // MFMAs) was built and is bit-identical, but as scheduled by hipcc it is 11 % slower at K = 256 and spills at K = 512
     // (profiles/r03_experiments.txt).
-    if (LIN1_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
-
     for (int i = tid * 4; i < g.F; i += 512 * 4) *reinterpret_cast<float4 *>(bias_lds + i) = *reinterpret_cast<const float4 *>(g.bias + i);
 
     // ---- weight ring: block -> slot; wave w requests rows 4 w .. 4 w + 3 of a block, one LDS-DMA instruction per row ----
@@ -169,7 +148,6 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     const char *const w_rows = reinterpret_cast<const char *>(g.W) + (size_t)(4 * wave) * ROWB;  // row 4 w of block 0
     auto issue_piece = [&](const char *src, unsigned dst, auto ic) __attribute__((always_inline)) {
         constexpr int I = decltype(ic)::value;
-        if (LIN1_PROBE & 8) return;
         const unsigned ls = lane_src;  // (an odr-use: a generic lambda does not capture a variable that only appears as an asm operand)
         if (C::LPR == 64 || lane < C::LPR) {
             // (s_nop 4 on the first piece: src / dst may come straight from a scalar ALU instruction and nothing pads the 5 wait states of
@@ -231,7 +209,6 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     // previous block, whose slot is free for the block two ahead.
     constexpr bool B2 = LIN1_B2 != 0 && K <= 256;
     auto step_head = [&](auto flushed_c) __attribute__((always_inline)) {
-        if (LIN1_PROBE & 16) return;
         if (B2) {  // (head of a pair of blocks: both were requested two steps ago, behind them only the previous step's slab stores)
             if (decltype(flushed_c)::value) wait_vmcnt<PPW>();
             else wait_vmcnt<0>();
@@ -277,21 +254,13 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         for (int i = 0; i < 2; ++i) pk[i] = *reinterpret_cast<const LDS_PTR(u32x4)>(rd0 + 1024 * (2 * half + i));
     };
     auto flush_store = [&](int half, const u32x4 (&pk)[2]) __attribute__((always_inline)) {
-        if (LIN1_PROBE & 4) return;
-        if (LIN1_ALL_PLAIN) {
-            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(fl_voff + (2 * half) * fl_stride8), "v"(pk[0]), "s"(fl_base) : "memory");
-            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(fl_voff + (2 * half + 1) * fl_stride8), "v"(pk[1]), "s"(fl_base) : "memory");
-            return;
-        }
         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(fl_voff + (2 * half) * fl_stride8), "v"(pk[0]), "s"(fl_base) : "memory");
         asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(fl_voff + (2 * half + 1) * fl_stride8), "v"(pk[1]), "s"(fl_base) : "memory");
     };
     auto flush_store_visible = [&](int half, const u32x4 (&pk)[2]) __attribute__((always_inline)) {
-        if (LIN1_PROBE & 4) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            if (LIN1_DRAIN_NT) __builtin_nontemporal_store(pk[i], reinterpret_cast<u32x4 *>(const_cast<char *>(fl_base) + (size_t)(fl_voff + (2 * half + i) * fl_stride8)));
-            else *reinterpret_cast<u32x4 *>(const_cast<char *>(fl_base) + (size_t)(fl_voff + (2 * half + i) * fl_stride8)) = pk[i];
+            __builtin_nontemporal_store(pk[i], reinterpret_cast<u32x4 *>(const_cast<char *>(fl_base) + (size_t)(fl_voff + (2 * half + i) * fl_stride8)));
     };
     auto put_group = [&](int ii, int q, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
         const u32x2 pk = {pack2(v0, v1), pack2(v2, v3)};
@@ -362,7 +331,7 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     // and no more than one slice's temporaries are live.  A fragments are requested PD k-steps ahead of the MFMA that takes them.
     auto step = [&](auto sec_c, auto par_c, auto mfma_c, auto epi_c, auto side) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
-        constexpr bool DO_MFMA = decltype(mfma_c)::value != 0 && !(LIN1_PROBE & 2), DO_EPI = decltype(epi_c)::value != 0;
+        constexpr bool DO_MFMA = decltype(mfma_c)::value != 0, DO_EPI = decltype(epi_c)::value != 0;
         constexpr int MPS = KS / 8, PD = LIN1_PD, MH = (MPS + 1) / 2;
         f32x16 &ac = PAR ? acc0 : acc1;
         const f32x16 &ae = PAR ? acc1 : acc0;
@@ -383,14 +352,11 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
                 if (DO_MFMA) {
                     const int ks = s * MPS + m;
                     ac = mfma32(fr[ks % PD], xreg[ks], ac);
-                    if (ks + PD < KS && !(LIN1_PROBE & 64)) fr[ks % PD] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * (ks + PD)));
+                    if (ks + PD < KS) fr[ks % PD] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * (ks + PD)));
                 }
             }
             if (MH == MPS) { LIN1_SIDE(0) LIN1_SIDE(1) LIN1_SIDE(2) LIN1_SIDE(3) LIN1_SIDE(4) LIN1_SIDE(5) LIN1_SIDE(6) LIN1_SIDE(7) }  // (one MFMA per slice)
-            if (DO_EPI) {
-                if (LIN1_PROBE & 1) epi_slice(std::integral_constant<int, LIN1_V>(), s, ae, PAR, c0, c1);  // (keeps the accumulators live)
-                else epi_slice(sec_c, s, ae, PAR, c0, c1);
-            }
+            if (DO_EPI) epi_slice(sec_c, s, ae, PAR, c0, c1);
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef LIN1_SIDE
@@ -399,43 +365,12 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     std::integral_constant<int, 0> I0;
     std::integral_constant<int, 1> I1;
     auto no_side = [](auto) __attribute__((always_inline)) {};
-    unsigned long long dbg_sum[4] = {0, 0, 0, 0};
-    unsigned long long dbg_seg[4] = {0, 0, 0, 0};  // (probe builds) per segment: activation load + wait + barrier, first two steps, drain + flush, count
-    auto kstamp = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned long long t;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-        return t;
-    };
-    unsigned long long dbg_split[3] = {0, 0, 0};  // later segments: older operations done, activation loads done, barrier
-    unsigned long long dbg_ph[4] = {0, 0, 0, 0};  // later segments: compute-only step, all fused steps, next segment's requests, drain + flush
-    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
-    unsigned long long dbg_c0 = 0, dbg_r0 = 0;  // (probe builds) core-clock and constant 100 MHz stamps at kernel entry: the clock the chip holds
-    if (LIN1_PROBE & 128) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_c0), "=s"(dbg_r0)::"memory");
     // fused step: MFMAs of block e + 1 beside the epilogue of block e (parity PAR = e & 1, section SEC).  FLUSH (PAR == 0 steps except the first
     // of a segment): the slab (e - 2, e - 1) is complete in the staging image and leaves during this step; PREV_FLUSHED: the previous step did
-#if LIN1_ATTN_PROBE
-    unsigned attn_probe_sink = 0;
-#endif
     auto fused = [&](auto sec_c, auto par_c, auto flush_c, auto prev_c, int e) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool FLUSH = decltype(flush_c)::value != 0;
-        unsigned long long t0 = 0, t1 = 0, t2 = 0;
-        auto stamp = [&]() __attribute__((always_inline)) {
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long t;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-            return t;
-        };
-        if (LIN1_PROBE & 128) t0 = stamp();
         if (!B2 || PAR == 1) step_head(prev_c);  // (B2: the pair (e + 1, e + 2) starts with the odd e)
-        if (B2 && LIN1_B2 >= 2) {  // (wave-uniform branch: the builtin takes a constant)
-            if ((((wave >> 2) ^ PAR) & 1) != 0) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-        if (LIN1_PROBE & 128) t1 = stamp();
         u32x4 pk[2];
         if (FLUSH) flush_setup(e - 2);
         const char *src = req_src(dma_blk);
@@ -445,7 +380,6 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         const char *src2 = req_src(blk2);
         const unsigned dst2 = req_dst(next_slot(dma_slot));
         init_acc(PAR ? acc0 : acc1, e + 1);
-        if (LIN1_PROBE & 128) t2 = stamp();
         step(sec_c, par_c, I1, I1, [&](auto sl) __attribute__((always_inline)) {
             constexpr int SL = decltype(sl)::value;
             if (FLUSH) {  // slab stores: rows read just ahead of their stores, all of it ahead of this step's first staging write
@@ -470,33 +404,6 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
             advance(dma_blk);
             advance(dma_blk);
             dma_slot = next_slot(next_slot(dma_slot));
-        }
-#if LIN1_ATTN_PROBE
-        // (harness only, results unchanged but time added on purpose) the work a fused spatial attention would put into this wave once per
-        // head - 16 of the 80 blocks of a tile at cfg 2: 32 MFMAs with one LDS fragment read each (QK^T and PV of 32 queries x 256 keys),
-        // 128 v_exp_f32 and 64 packs per lane - as a separate phase behind the step, the way an in-order wave would run it
-        if (e % 5 == 4) {
-            f32x16 da;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) da[i] = 0.0f;
-            const char *sbp = smem + slot_c * BLK + aoff;
-#pragma unroll
-            for (int ks = 0; ks < 32; ++ks) da = mfma32(as_bf16x8(*reinterpret_cast<const u32x4 *>(sbp + 32 * (ks % KS))), xreg[ks % KS], da);
-#pragma unroll
-            for (int rep = 0; rep < 8; ++rep)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) da[i] = __builtin_amdgcn_exp2f(da[i] * 0.001f);
-            unsigned acc_bits = 0;
-#pragma unroll
-            for (int rep = 0; rep < 8; ++rep)
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) acc_bits ^= pack2(da[i] + (float)rep, da[i + 1]);
-            attn_probe_sink ^= acc_bits;
-        }
-#endif
-        if (LIN1_PROBE & 128) {
-            const unsigned long long t3 = stamp();
-            dbg_sum[0] += t1 - t0; dbg_sum[1] += t2 - t1; dbg_sum[2] += t3 - t2; dbg_sum[3] += 1;
         }
     };
     // fused steps for the epilogue blocks [ea, eb) of one section; every even step flushes (the segment's first fused step is not run here)
@@ -564,8 +471,6 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     __syncthreads();  // bias vector in LDS
     while (left > 0) {  // one segment = blocks [b0, b1) of one token tile; b0, b1 even
         const int b1 = NB - b0 < left ? NB : b0 + left;
-        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
-        if (LIN1_PROBE & 128) ts0 = kstamp();
         n_wave = tile * 256 + wave * 32;
         row_q = reinterpret_cast<const char *>(g.qkv) + (size_t)n_wave * stride_q;
         row_z = reinterpret_cast<const char *>(g.z) + (size_t)n_wave * stride_z - 4 * (size_t)g.HHD;  // (z column of feature f: f - 2 HHD)
@@ -581,16 +486,10 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         // (see the end of the loop): vmcnt(4) covers the loads and every ring request, and leaves exactly those stores in flight - their
         // acknowledgements take ~ 10 000 cycles under this kernel's write stream and used to be waited for at every tile boundary
         // (profiles/r03_experiments.txt).  Then the barrier: a wave may read a block only once every wave's pieces of it have landed.
-        if (LIN1_PROBE & 128) ts3 = kstamp();
         if (first_seg) wait_vmcnt<0>();
         else wait_vmcnt<4>();
-        if (LIN1_PROBE & 128) ts2 = kstamp();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (LIN1_PROBE & 128) {
-            ts1 = kstamp();
-            if (dbg_seg[3] > 0) { dbg_split[0] += ts3 - ts0; dbg_split[1] += ts2 - ts3; dbg_split[2] += ts1 - ts2; }
-        }
         issue(dma_blk, dma_slot);
         advance(dma_blk);
         dma_slot = next_slot(dma_slot);
@@ -598,15 +497,9 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
             issue(dma_blk, dma_slot);
             advance(dma_blk);
             dma_slot = next_slot(dma_slot);
-            if (LIN1_B2 >= 2) {
-                if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
         }
         init_acc(acc0, b0);
-        if (LIN1_PROBE & 128) tp0 = kstamp();
         step(SV, I1, I1, I0, no_side);
-        if (LIN1_PROBE & 128) tp1 = kstamp();
         // the segment's first fused step (e = b0, even): nothing to flush yet
         const int e_end = b1 - 1;
         if (b0 < 2 * qb) {
@@ -645,7 +538,6 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         // rows are requested first, so that they are older than the slab's stores (which the next segment then does not wait for).  These four
         // stores are ordinary (compiler-visible) stores: hipcc then knows they are younger than the loads and waits with vmcnt(4), not vmcnt(0),
         // where it consumes the loaded registers.
-        if (LIN1_PROBE & 128) tp2 = kstamp();
         const int left_next = left - (b1 - b0);
         co_ready = false;
         if (left_next > 0) {  // (uniform) the next segment: tile + 1 from block 0, i.e. the q section
@@ -660,7 +552,6 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
             }
             asm volatile("" ::: "memory");
         }
-        if (LIN1_PROBE & 128) tp3 = kstamp();
         {
             const int e = b1 - 1;
             if (e < 2 * qb) {
@@ -681,27 +572,6 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         tile += 1;
         b0 = 0;
         first_seg = false;
-        if (LIN1_PROBE & 128) {
-            const unsigned long long tp4 = kstamp();
-            if (dbg_seg[3] > 0) { dbg_ph[0] += tp1 - tp0; dbg_ph[1] += tp2 - tp1; dbg_ph[2] += tp3 - tp2; dbg_ph[3] += tp4 - tp3; }
-            dbg_seg[3] += 1;
-        }
     }
-#if LIN1_ATTN_PROBE
-    if (attn_probe_sink == 0x9E3779B9u && g.dbg) g.dbg[0] = attn_probe_sink;  // (keeps the probe's work alive)
-#endif
     wait_vmcnt<0>();  // the ring's run-ahead requests must not land in LDS after the workgroup has gone
-    if ((LIN1_PROBE & 128) && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) g.dbg[((size_t)blockIdx.x * 8 + wave) * 4 + k] = dbg_sum[k];
-        unsigned long long c1, r1;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
-        unsigned long long *x = g.dbg + (size_t)gridDim.x * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 10;
-        x[0] = c1 - dbg_c0; x[1] = r1 - dbg_r0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) x[2 + k] = dbg_seg[k];
-        x[2] = dbg_split[0]; x[3] = dbg_split[1]; x[4] = dbg_split[2];  // (replaces the coarser sums)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) x[6 + k] = dbg_ph[k];
-    }
 }

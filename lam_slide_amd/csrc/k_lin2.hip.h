@@ -45,18 +45,8 @@ struct Lin2Args {
     unsigned tpt_magic;   // floor(2^32 / tpt) + 1 (0 when tpt == 1)
     int slices, rpx;      // feature slices of 128 (F / 128) and token ranges per XCD: grid = 8 * slices * rpx
     int gate_rows;        // rows of the LDS gate table (>= the trajectories one token range spans; host-checked)
-    unsigned long long *dbg;  // probe builds only
 };
 
-#ifndef LIN2_PROBE
-#define LIN2_PROBE 0  // tools/lin2_harness.hip only (results wrong): 1 no epilogue arithmetic + residual traffic, 2 no MFMAs, 4 no stores, 8 no token DMA, 32 no residual DMA, 128 cycle stamps, 256 every MFMA twice (a second accumulator on the same operands: what a 64-feature wave would issue per fragment), 512 every token-chunk request wraps inside a 4-block window of its range (all of them L2 hits: the ceiling of anything that turns the slices' shared misses into hits - leader rotation), 1024 the hi waves also store a bf16 row segment per token (64 B per row and wave: the `a` a fused LayerNorm would write) to Lin2Args::dbg
-#endif
-#ifndef LIN2_HI_FIRST
-#define LIN2_HI_FIRST 0  // 1: waves 0-3 (the older half, which wins the issue arbitration) finish the chains and run the epilogue
-#endif
-#ifndef LIN2_DEPHASE
-#define LIN2_DEPHASE 0  // (measured: 0.431 vs 0.418 ms per cfg-2 launch: two back-to-back requests cost more than they save) 1: lo wave p issues its token-row requests behind the MFMAs i = p (mod 4) (0: every wave behind every second MFMA)
-#endif
 #ifndef LIN2_PD
 #define LIN2_PD 2  // token fragments requested this many k-steps ahead of their MFMA
 #endif
@@ -120,7 +110,7 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hf = lane >> 5;
-    const int hi = LIN2_HI_FIRST ? 1 - (wave >> 2) : (wave >> 2);  // 0: first half of every chain, 1: second half + epilogue
+    const int hi = wave >> 2;  // 0: first half of every chain, 1: second half + epilogue
     const int p = wave & 3;                                        // pair = 32-feature group of the slice
 
     // workgroup -> (feature slice, token range): the slices of one range share an XCD (blocks b and b + 8 do: speed only)
@@ -174,7 +164,6 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
         return reinterpret_cast<const char *>(((unsigned long long)hi32 << 32) | lo32);
     };
     auto dma_row = [&](const char *src_, unsigned dst_, unsigned voff) __attribute__((always_inline)) {
-        if (LIN2_PROBE & 8) return;
         const char *src = uni_ptr(src_);
         const unsigned dst = __builtin_amdgcn_readfirstlane(dst_);
         if (C::LPR == 64 || lane < C::LPR)
@@ -185,7 +174,6 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
     auto chunk_src = [&](int m, int j, unsigned &voff) __attribute__((always_inline)) {
         int mh = min(max(m - 1, 0), nblk - 1), ml = min(m, nblk - 1);
         voff = ml > mh ? voff_next : voff_same;
-        if (LIN2_PROBE & 512) mh &= 3;
         return reinterpret_cast<const char *>(g.Z) + ((size_t)(blk0 + mh) * 32 + 8 * p) * (2 * K) + (size_t)j * (2 * KC);
     };
 
@@ -194,61 +182,29 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-    f32x16 acc2;  // (LIN2_PROBE & 256 only)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
 
     // one chunk's MFMAs (chunk j of the block, in ring slot `slot`) with side jobs in their shadows: side(i) runs behind MFMA i
     auto chain = [&](auto jc, int slot, bool zero_start, auto side) __attribute__((always_inline)) {
         constexpr int J = decltype(jc)::value;
         const char *sb = smem + slot * CHUNK + boff;
         bf16x8 fr[PD];
-        if (!(LIN2_PROBE & 2)) {
 #pragma unroll
-            for (int i = 0; i < PD; ++i) fr[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * i));
-        }
+        for (int i = 0; i < PD; ++i) fr[i] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * i));
 #pragma unroll
         for (int i = 0; i < MPC; ++i) {
-            if (!(LIN2_PROBE & 2)) {
-                if (J == 0 && i == 0 && zero_start) {
-                    f32x16 z;
+            if (J == 0 && i == 0 && zero_start) {
+                f32x16 z;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) z[e] = 0.0f;
-                    acc = mfma32(wreg[J * MPC + i], fr[i % PD], z);
-                } else
-                    acc = mfma32(wreg[J * MPC + i], fr[i % PD], acc);
-                if (LIN2_PROBE & 256) acc2 = mfma32(wreg[J * MPC + i], fr[i % PD], acc2);  // (timing probe: a second feature tile's MFMAs on the same fragments)
-                if (i + PD < MPC) fr[i % PD] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * (i + PD)));
-            }
+                for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+                acc = mfma32(wreg[J * MPC + i], fr[i % PD], z);
+            } else
+                acc = mfma32(wreg[J * MPC + i], fr[i % PD], acc);
+            if (i + PD < MPC) fr[i % PD] = as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + 32 * (i + PD)));
             side(i);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     char *const exch = smem + C::EXCH + p * 4096;
-    // (probe builds) cycle sums: [0] counted wait at the head of a chunk-step / for the residual rows, [1] barrier, [2] everything else, [3] count
-    unsigned long long dbg_sum[4] = {0, 0, 0, 0};
-    auto kstamp = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned long long t;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-        return t;
-    };
-    unsigned long long dbg_c0 = 0, dbg_r0 = 0, t_last = 0;
-    if (LIN2_PROBE & 128) {
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_c0), "=s"(dbg_r0)::"memory");
-        t_last = dbg_c0;
-    }
-    auto dbg_out = [&]() __attribute__((always_inline)) {
-        if ((LIN2_PROBE & 128) && lane == 0) {
-            unsigned long long c1, r1;
-            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
-            unsigned long long *x = g.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
-            x[0] = c1 - dbg_c0; x[1] = r1 - dbg_r0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[2 + k] = dbg_sum[k];
-        }
-    };
     auto next_slot = [](int s) __attribute__((always_inline)) { return s + 1 == NS ? 0 : s + 1; };
 
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the stationary weights
@@ -276,17 +232,9 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
             const bool work = m < nblk;     // (the last block-step only feeds the hi waves)
             auto step = [&](auto jc) __attribute__((always_inline)) {
                 // the chunk to compute was requested NS - 1 chunk-steps ago; younger: the 8 requests of each of the NS - 2 chunks behind it
-                unsigned long long ta = 0, tb = 0, tc = 0;
-                if (LIN2_PROBE & 128) ta = kstamp();
-                if (!(LIN2_PROBE & 8)) wait_vmcnt<8 * (NS - 2)>();
-                if (LIN2_PROBE & 128) tb = kstamp();
+                wait_vmcnt<8 * (NS - 2)>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (LIN2_PROBE & 128) {
-                    tc = kstamp();
-                    dbg_sum[0] += tb - ta; dbg_sum[1] += tc - tb; dbg_sum[2] += ta - t_last; dbg_sum[3] += 1;
-                    t_last = tc;
-                }
                 // request the chunk NS - 1 ahead (its slot held the previous chunk, which every wave has left)
                 unsigned voff;
                 const char *src = chunk_src(rq_m, rq_j, voff);
@@ -295,17 +243,12 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
                 if (work) {
                     // the four lo waves run in lockstep behind the barrier: requests issued at the same point of the chain arrive at the
                     // vector-memory unit together and queue (measured: ~110 cycles per instruction, 8 per chunk-step in each wave's in-order
-                    // stream beside its 16 MFMAs).  Wave p therefore issues behind the MFMAs i = p (mod 4) only, 8 / (MPC / 4) rows at a time
-                    constexpr int SLOTS = MPC / 4 > 0 ? MPC / 4 : 1, PER = (8 + SLOTS - 1) / SLOTS;
+                    // stream beside its 16 MFMAs).  Issuing them wave by wave behind the MFMAs i = p (mod 4) was measured and dropped (0.431 vs
+                    // 0.418 ms per cfg-2 launch: two back-to-back requests cost more than they save): one row behind every second MFMA
                     chain(jc, slot, true, [&](int i) __attribute__((always_inline)) {
-                        if (LIN2_DEPHASE ? ((i & 3) == p && (i >> 2) < SLOTS) : (i % 2 == 1 && i / 2 < 8)) {
-                            const int first = LIN2_DEPHASE ? (i >> 2) * PER : i / 2, cnt = LIN2_DEPHASE ? PER : 1;
-#pragma unroll
-                            for (int k = 0; k < cnt; ++k)
-                                if (first + k < 8) dma_row(src + (size_t)(first + k) * (2 * K), dst + (first + k) * PITCH, voff);
-                        }
+                        if (i % 2 == 1 && i / 2 < 8) dma_row(src + (size_t)(i / 2) * (2 * K), dst + (i / 2) * PITCH, voff);
                     });
-                    if (!LIN2_DEPHASE && MPC < 16) {
+                    if (MPC < 16) {
 #pragma unroll
                         for (int i = MPC / 2; i < 8; ++i) dma_row(src + (size_t)i * (2 * K), dst + i * PITCH, voff);
                     }
@@ -324,8 +267,6 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
             }
         }
         wait_vmcnt<0>();  // the run-ahead requests must not land in LDS after the workgroup has gone
-        if ((LIN2_PROBE & 256) && acc2[0] + acc2[7] + acc2[15] == 12345.678f && g.dbg) g.dbg[1] = 1;
-        dbg_out();
         return;
     }
 
@@ -349,12 +290,10 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
         for (int i = 0; i < 4; ++i) {
             const unsigned n = (unsigned)min((blk0 + b) * 32 + 8 * i + tr, g.N - 1);
             const unsigned voff = n * row_bytes + 4u * f0 + 16u * ch, dst = __builtin_amdgcn_readfirstlane(hbuf_lds + hb_off(b) + i * 1024);
-            if (!(LIN2_PROBE & 33))
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(g.h), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(g.h), "s"(dst) : "memory");
         }
     };
     auto epi_math = [&](int b) __attribute__((always_inline)) {  // block b: register group q = features 8 q + 4 hf .. + 3 of token r
-        if (LIN2_PROBE & 1) return;
         const int l = opaque_lane(), rr = l & 31, hh = l >> 5;
         const unsigned n = (unsigned)min((blk0 + b) * 32 + rr, g.N - 1);
         const unsigned traj = g.mod_stride ? (g.tpt_magic ? __umulhi(n, g.tpt_magic) : n) - traj_lo : 0u;
@@ -374,12 +313,10 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
         }
     };
     auto epi_store = [&](int b, int i, bool ragged) __attribute__((always_inline)) {  // rows 8 i .. 8 i + 7 of block b, whole 128-byte segments
-        if (LIN2_PROBE & 1) return;
         const int l = opaque_lane(), tr = l >> 3, ch = (l & 7) ^ (tr & 7);
         const u32x4 v = *reinterpret_cast<const u32x4 *>(hbuf + hb_off(b) + i * 1024 + l * 16);
         const int n = (blk0 + b) * 32 + 8 * i + tr;
         const unsigned voff = (unsigned)min(n, g.N - 1) * row_bytes + 4u * f0 + 16u * ch;
-        if (LIN2_PROBE & 4) return;
         if (ragged) {
             if (n < g.N) store16(reinterpret_cast<char *>(g.h) + voff, v, true);
         } else
@@ -403,30 +340,16 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
         const int B = m - 1;
         auto step = [&](auto jc) __attribute__((always_inline)) {
             constexpr int J = decltype(jc)::value;
-            unsigned long long ta = 0, tb = 0;
-            if (LIN2_PROBE & 128) ta = kstamp();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (LIN2_PROBE & 128) {
-                tb = kstamp();
-                dbg_sum[1] += tb - ta; dbg_sum[2] += ta - t_last; dbg_sum[3] += 1;
-                t_last = tb;
-            }
             if (J == 0) {
                 // the finished tile's arithmetic (on the accumulators, against the LDS image of its residual rows), then take over the next
                 // chain from the lo wave
                 if (B >= 1) {
-                    if (!(LIN2_PROBE & 33)) {
-                        if (!HB2) wait_vmcnt<0>();
-                        else if (B >= 2) wait_vmcnt<8 + ((LIN2_PROBE & 1024) ? 2 : 0)>();
-                        else wait_vmcnt<4>();
-                    }
+                    if (!HB2) wait_vmcnt<0>();
+                    else if (B >= 2) wait_vmcnt<8>();
+                    else wait_vmcnt<4>();
                     asm volatile("" ::: "memory");
-                    if (LIN2_PROBE & 128) {
-                        const unsigned long long td = kstamp();
-                        dbg_sum[0] += td - t_last;
-                        t_last = td;
-                    }
                     epi_math(B - 1);
                 }
                 const int l = opaque_lane();
@@ -444,16 +367,6 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
             if (J == 1 && B >= 1) {
 #pragma unroll
                 for (int k = IN_CHAIN; k < 4; ++k) epi_store(B - 1, k, false);
-                if (LIN2_PROBE & 1024) {  // (timing probe) 32 rows x 64 B of bf16 per wave and block: two 16-row instructions, 4 lanes per row
-                    const int l = opaque_lane();
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const u32x4 v = *reinterpret_cast<const u32x4 *>(hbuf + hb_off(B - 1) + k * 1024 + l * 16);
-                        const unsigned n = (unsigned)min((blk0 + B - 1) * 32 + 16 * k + (l >> 2), g.N - 1);
-                        const unsigned voff = n * (2u * g.F) + 2u * f0 + 16u * (l & 3);
-                        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(g.dbg) : "memory");
-                    }
-                }
             }
             slot = next_slot(slot);
         };
@@ -470,6 +383,4 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
         for (int i = 0; i < 4; ++i) epi_store(b, i, ragged);
     }
     wait_vmcnt<0>();
-    if ((LIN2_PROBE & 256) && acc2[0] + acc2[7] + acc2[15] == 12345.678f && g.dbg) g.dbg[1] = 1;
-    dbg_out();
 }

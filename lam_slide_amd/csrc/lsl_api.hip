@@ -279,12 +279,13 @@ int lsl_sample_ex(lsl_model *m, const lsl_io *io, const lsl_step_ex *steps, int3
         for (int s = 0; s < n_steps; ++s) ps[s] = lsl_step{steps[s].t, steps[s].ax, steps[s].am, steps[s].aw};
         return resident_sample(m, io, ps.data(), n_steps, noise, seed, elem_offset, trace, workspace, st);
     }
-    // hipGraph replay (opt-in).  LSL_GRAPH: 0 off (default), 1 for launch-bound calls (at most 64 Ki tokens per pass and 4096 launches) whose
-    // arguments repeat, 2 for every call of at most 4096 launches: the first appearance of an argument set runs eagerly (it also initialises
-    // the per-kernel attributes), the second is captured, later ones are replayed.  Measured on MI355X (tools/latency_small_batch.py): a
-    // 10-update pedestrian call (~600 launches) takes 3.38 ms eagerly and 3.23 ms replayed - the floor of the small-batch configs is the
-    // GPU-side cost of ~600 dependent tiny kernels (5 us each), not the host launches, so replay buys 0-4 % and stays off by default.
-    static const int use_graph = env_int("LSL_GRAPH", 0);
+    // hipGraph replay.  LSL_GRAPH: 1 (default since round 6) for launch-bound calls (at most 64 Ki tokens per pass and 4096 launches) whose
+    // arguments repeat, 2 for every call of at most 4096 launches, 0 off: the first appearance of an argument set runs eagerly (it also
+    // initialises the per-kernel attributes), the second is captured, later ones are replayed.  Bit-identical to the eager path
+    // (test_graph_replay_matches_eager_bits).  Measured on MI355X (tools/latency_small_batch.py, profiles/r06_small_launches.txt): a
+    // 10-update pedestrian call (~600 launches) 3.38 -> 3.23 ms, md17_bench B = 1 (50 updates) 30.0 -> 29.2 ms: the floor of the small-batch
+    // configs is the GPU-side cost of their dependent tiny kernels, replay removes the host-side gaps between them (0-4 %).
+    static const int use_graph = env_int("LSL_GRAPH", 1);
     const int passes = (io->B + chunk - 1) / chunk;
     const long est_launches = (long)passes * n_steps * (8L * m->d.depth + 6);
     const bool launch_bound = (size_t)chunk * io->T * io->L <= 65536;

@@ -220,28 +220,33 @@ class LatentSIV3(nn.Module):
         return ws
 
     @staticmethod
-    def graph_replay_enabled() -> bool:
-        return os.environ.get("LSL_GRAPH", "0") not in ("", "0")
+    def graph_replay_enabled(tokens: Optional[int] = None) -> bool:
+        """Whether the library may replay a captured hipGraph for a call of ``tokens`` (= B T L) tokens: LSL_GRAPH=1 (the default) for
+        launch-bound calls (at most 64 Ki tokens, the library's own rule in lsl_sample_ex), 2 for every call, 0 never."""
+        mode = os.environ.get("LSL_GRAPH", "1")
+        if mode in ("", "0"):
+            return False
+        return mode != "1" or tokens is None or tokens <= 65536
 
-    def staged(self, tag: str, src: Tensor, dtype: torch.dtype, device, fresh: bool = False) -> Tensor:
-        """``src`` as a contiguous ``dtype`` tensor on ``device`` for the library.  By default nothing persists: ``fresh`` (the state,
-        which the sampler updates in place) gets a private copy, everything else is passed through when it already has the right layout.
-        Only with hipGraph replay switched on (LSL_GRAPH != 0) the copy goes into a persistent buffer per (tag, shape, device), so that
-        repeated calls hand the library the SAME pointers and ``lsl_sample`` can replay its captured graph; that cache is LRU-bounded
-        (8 buffers) and its users must run one sampling call at a time per model object."""
+    def staged(self, tag: str, src: Tensor, dtype: torch.dtype, device, fresh: bool = False, persistent: bool = False) -> Tensor:
+        """``src`` as a contiguous ``dtype`` tensor on ``device`` for the library.  Without ``persistent`` nothing persists: ``fresh`` (the
+        state, which the sampler updates in place) gets a private copy, everything else is passed through when it already has the right
+        layout.  ``persistent`` (calls the library may replay as a hipGraph: ``graph_replay_enabled``): the copy goes into a persistent
+        buffer per (tag, shape, device), so that repeated calls hand the library the SAME pointers and ``lsl_sample`` can replay its
+        captured graph; that cache is keyed per stream and LRU-bounded (16 buffers): one sampling call at a time per model object and stream."""
         device = torch.device(device)
-        if not self.graph_replay_enabled():
+        if not persistent:
             out = src.detach().to(device=device, dtype=dtype).contiguous()
             if fresh and out.data_ptr() == src.data_ptr():
                 out = out.clone()
             return out
-        key = (tag, tuple(src.shape), device)
+        key = (tag, tuple(src.shape), device, torch.cuda.current_stream(device).cuda_stream)  # (per stream, like the workspace)
         buf = self._pinned.get(key)
         if buf is None:
             buf = torch.empty(src.shape, dtype=dtype, device=device)
             self._pinned[key] = buf
         self._pinned.move_to_end(key)
-        while len(self._pinned) > 8:
+        while len(self._pinned) > 16:
             self._pinned.popitem(last=False)
         buf.copy_(src)
         return buf

@@ -602,13 +602,14 @@ class Sampler:
         self.last_seed = call_seed if needs_device_noise else None
         with torch.cuda.device(dev):
             net.ensure_packed(dev)
-            # the state is updated in place by the library: always a private copy (persistent buffers only under LSL_GRAPH, see staged())
-            x = net.staged("state", init, torch.float32, dev, fresh=True)
-            xc = net.staged("x_cond", model_kwargs["x_cond"], torch.float32, dev)
-            xm = net.staged("x_cond_mask", model_kwargs["x_cond_mask"], torch.int64, dev)
+            # the state is updated in place by the library: always a private copy (persistent buffers only for calls the library may replay as a hipGraph, see staged())
+            replay = net.graph_replay_enabled(tokens=int(init.shape[0]) * int(init.shape[1]) * int(init.shape[2]))
+            x = net.staged("state", init, torch.float32, dev, fresh=True, persistent=replay)
+            xc = net.staged("x_cond", model_kwargs["x_cond"], torch.float32, dev, persistent=replay)
+            xm = net.staged("x_cond_mask", model_kwargs["x_cond_mask"], torch.int64, dev, persistent=replay)
             yv = model_kwargs.get("y")
             if yv is not None:
-                yv = net.staged("y", yv, torch.float32, dev)
+                yv = net.staged("y", yv, torch.float32, dev, persistent=replay)
             io, keep = net.make_io(x, xc, xm, yv)
             ws = net.workspace(io.B, io.T, io.L, dev)
             if records is None:
@@ -639,7 +640,7 @@ class Sampler:
         # (extended records always run the general kernels: the trajectory-resident kernel implements the plain affine step only)
         self.last_kernels = "resident" if records is None and lib.lsl_sampler_path(net._handle, io.T, io.L) == 1 else "general"
         del keep
-        if net.graph_replay_enabled():
+        if replay:
             x = x.clone()  # the persistent buffer is overwritten by the next call
         if x.dtype != init.dtype:
             x = x.to(init.dtype)

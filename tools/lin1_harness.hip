@@ -11,7 +11,11 @@
 #include <vector>
 
 #include "../lam_slide_amd/csrc/k_gemm.hip.h"
+#ifdef LIN1_PROBED  // tools/build_harness.sh lin1: the product kernel + tools/experiments/lin1_probes.patch (timing arms, cycle stamps: results wrong when set)
+#include "_exp/k_lin1_probed.hip.h"
+#else
 #include "../lam_slide_amd/csrc/k_lin1.hip.h"
+#endif
 
 #define CK(x)                                                                  \
     do {                                                                       \
@@ -80,7 +84,11 @@ void run_case(int N, int D, int H, int mlp_ratio, int iters, int grid_new, int p
     unsigned long long *dbg;
     CK(hipMalloc(&dbg, 256 * 8 * 14 * 8));
     CK(hipMemset(dbg, 0, 256 * 8 * 14 * 8));
+#ifdef LIN1_PROBED
     Lin1Args la{W, X, b, rq, rk, qkv1, z1, F, N, HHD, M, pdiv, pmod, magic_of(pdiv), magic_of(pmod), inv_hd, premul, 1, dbg};
+#else
+    Lin1Args la{W, X, b, rq, rk, qkv1, z1, F, N, HHD, M, pdiv, pmod, magic_of(pdiv), magic_of(pmod), inv_hd, premul, 1};
+#endif
     auto knew = k_linear1_ts<HDP, K>;
     const size_t lds_new = Lin1Cfg<HDP, K>::lds_bytes(F);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(knew), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));

@@ -11,7 +11,12 @@
 #include <vector>
 
 #include "../lam_slide_amd/csrc/k_gemm.hip.h"
+#ifdef LIN2_PROBED  // tools/build_harness.sh lin2: the product kernel + tools/experiments/lin2_probes.patch (timing arms, cycle stamps: results wrong when set)
+#include "_exp/k_lin2_probed.hip.h"
+#else
 #include "../lam_slide_amd/csrc/k_lin2.hip.h"
+#define LIN2_PROBE 0
+#endif
 
 #ifndef LIN2_HB2
 #define LIN2_HB2 1
@@ -91,7 +96,11 @@ void run_case(int N, int F, int tpt, int shared, int iters, int rpx_arg) {
     const size_t dbg_bytes = (LIN2_PROBE & 1024) ? (size_t)N * F * 2 + 4096 : (size_t)256 * 8 * 16 * 8;  // (probe 1024: the bf16 rows a fused LayerNorm would write)
     CK(hipMalloc(&dbg, dbg_bytes));
     CK(hipMemset(dbg, 0, dbg_bytes));
+#ifdef LIN2_PROBED
     Lin2Args la{Wp, Z, b, gate, h1, F, N, mod_stride, tpt, magic_of(tpt), slices, rpx, gate_rows, dbg};
+#else
+    Lin2Args la{Wp, Z, b, gate, h1, F, N, mod_stride, tpt, magic_of(tpt), slices, rpx, gate_rows};
+#endif
     auto knew = k_linear2_ws<K, NCH_, NS_, LIN2_HB2 != 0>;
     const size_t lds_new = C2::lds_bytes(gate_rows);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(knew), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
