@@ -702,6 +702,47 @@ def test_f9_real_lightning_sample_on_device(golden, dev):
     parity("f9.decoded", rel_l2(pos, f["pos"]), 3e-4)
 
 
+def test_f11_real_pedestrian_k_sample_evaluation_on_device(golden, dev):
+    """F11: what the reference's REAL pedestrian CondWrapper produced in the build container - `prepare_batch` (y = Embedding(cond_scene),
+    second_stage/pedestrian.py:242-251) and the K = 20 `test_step` loop (:186-212: K sequential sample() calls, future frames, real agents,
+    best-of-K ADE / FDE) - against the drop-in on the device at the true pedestrian shape (T = 20, L = 2: the trajectory-resident kernel):
+    Stage1Encoder -> one fused K-sample call -> Stage1Decoder -> min_ade_fde (`best_of_k_errors`), with the fixture's K initial noises."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler, Stage1Decoder, Stage1Encoder
+    from lam_slide_amd.sampling import best_of_k_errors
+    from oracle import latent_net
+    f = golden("f11_pedestrian_k.npz")
+    B, T, A, L, K, c0, c1, n = (int(v) for v in f["meta"])
+    sh = shape_from(f.group("shape"))
+    net = build_net(sh, latent_net.random_params(sh, seed=int(f["weight_seed"])), dev)
+    s1 = f.group("stage1")
+    enc = Stage1Encoder(s1, num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16)
+    dec = Stage1Decoder(s1, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+    flat = lambda t: t.reshape(-1, *t.shape[2:])  # noqa: E731
+    pos = f["pos"].clone()
+    pos[:, c1:] = 0  # (the reference hides the future frames from the encoder: :175-176)
+    lat = enc.encode(flat(pos @ f["lift"]).to(dev), flat(f["entities"]).to(dev), flat(f["attention_mask"]).to(dev)).reshape(B, T, L, 32)
+    y = f["embedding"].to(dev)[f["cond_scene"].long().to(dev)]  # CondWrapper.prepare_batch
+    assert torch.equal(y.cpu(), f["y"])
+    drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(c0, c1), mask_cond_mean=True,
+                             sampling_kwargs={"sampling_method": "euler", "num_steps": n})
+    ent = flat(f["entities"]).to(dev)
+    seen = {}
+
+    def decode(z):  # [K*B, T, L, C] -> [K*B, T, A, 3]
+        seen["final"] = z
+        p = dec.decode(z.reshape(-1, L, 32), ent.repeat(z.shape[0] // B, 1))
+        seen["pos"] = p.reshape(z.shape[0], T, A, 3)
+        return seen["pos"]
+
+    ades, fdes = best_of_k_errors(drv, lat, f["true_future"].to(dev), K, decode, agent_mask=f["attention_mask"][:, -1].to(dev), y=y,
+                                  inits=f["noises"].to(dev), num_runs=K)
+    assert drv.last_sampler.last_path == "fused" and drv.last_sampler.last_kernels == "resident"
+    parity("f11.finals", rel_l2(seen["final"].reshape(K, B, T, L, 32).cpu(), f["finals"]), 1e-3)
+    parity("f11.positions", rel_l2(seen["pos"].reshape(K, B, T, A, 3).cpu(), f["positions"]), 5e-4)
+    parity("f11.ade", rel_l2(ades.cpu(), f["ades"]), 5e-4)
+    parity("f11.fde", rel_l2(fdes.cpu(), f["fdes"]), 5e-4)
+
+
 def test_graph_replay_matches_eager_bits(dev):
     """LSL_GRAPH=2: repeated sampling calls with the same buffers are captured into a hipGraph on their second appearance and replayed
     afterwards; results must be the bits of the eager path, also when the INPUT VALUES change between replays (the graph reads through

@@ -173,3 +173,33 @@ def test_f9_real_lightning_module_sample_chain(golden):
     assert rel_l2(final, f["final"]) < 5e-6
     pos = harness.decode(s1, harness.DecoderShape(), flat(final), flat(f["entities"])).reshape(f["pos"].shape)
     assert rel_l2(pos, f["pos"]) < 5e-6
+
+
+def test_f11_real_pedestrian_cond_wrapper_k_loop(golden):
+    """F11 = the reference's real pedestrian CondWrapper (second_stage/pedestrian.py, built by its own __init__ from the reference YAMLs
+    in the build container): `prepare_batch` with the class vector y = Embedding(cond_scene) (:242-251) and the K = 20 `test_step` loop
+    (:186-212) with one stored initial noise per sample() call.  The oracle chain reproduces the conditioning, every sample's final latents
+    and decoded positions, and the best-of-K ADE / FDE of the real (unpadded) agents."""
+    f = golden("f11_pedestrian_k.npz")
+    B, T, A, L, K, c0, c1, n = (int(v) for v in f["meta"])
+    sh = shape_from(f.group("shape"))
+    sd = latent_net.random_params(sh, seed=int(f["weight_seed"]))
+    s1 = f.group("stage1")
+    flat = lambda t: t.reshape(B * T, *t.shape[2:])  # noqa: E731
+    y = f["embedding"][f["cond_scene"].long()]
+    assert torch.equal(y, f["y"])  # CondWrapper.prepare_batch: an embedding lookup
+    pos = f["pos"].clone()
+    pos[:, c1:] = 0  # test_step hides the future frames from the encoder (:175-176)
+    lat = harness.encode(s1, harness.EncoderShape(num_latents=L), flat(pos @ f["lift"]), flat(f["entities"]), flat(f["attention_mask"])).reshape(B, T, L, 32)
+    xc, mask = harness.setup_conditioning(lat, (c0, c1), True)
+    assert torch.equal(mask, f["mask"]) and rel_l2(xc[:, :c1], f["x_cond"][:, :c1]) < 2e-6
+    finals = torch.stack([harness.sample_latents(sd, sh, otr.Transport("GVP", "data"), f["noises"][k], xc, mask, y, "ODE",
+                                                 {"sampling_method": "euler", "num_steps": n}) for k in range(K)])
+    assert rel_l2(finals, f["finals"]) < 5e-6
+    positions = harness.decode(s1, harness.DecoderShape(), finals.reshape(K * B * T, L, 32), flat(f["entities"]).repeat(K, 1)).reshape(K, B, T, A, 3)
+    assert rel_l2(positions, f["positions"]) < 5e-6
+    keep = f["attention_mask"][:, -1].reshape(-1).bool()
+    traj = positions[:, :, c1:].permute(1, 3, 0, 2, 4).reshape(B * A, K, T - c1, 3)[keep]
+    tgt = f["true_future"].permute(0, 2, 1, 3).reshape(B * A, T - c1, 3)[keep]
+    ades, fdes = harness.compute_errors(traj, tgt)
+    assert ades.shape == f["ades"].shape and rel_l2(ades, f["ades"]) < 5e-6 and rel_l2(fdes, f["fdes"]) < 5e-6

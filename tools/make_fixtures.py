@@ -16,6 +16,7 @@ Fixture families:
   f6_decode.npz     frozen stage-1 decode of latents -> positions (MD17 decoder shape, seeded weights)
   f7_encode.npz     frozen stage-1 Encoder + quant with a ragged entity mask (MD17 encoder shape, 48 latents)
   f8_decode_split.npz  DecoderQuerySplitter (peptide decoder: 1x1-conv latent extender), one latent<-query cross block, tanh GELU
+  f11_pedestrian_k.npz  the reference's REAL pedestrian CondWrapper: prepare_batch (class vector y) and the K = 20 test_step loop (ADE / FDE)
   f9_sample.npz     the reference's REAL LightningModule (second_stage/md17.py Wrapper built by its own __init__ from the reference YAML,
                     lightning_base.py sample / prepare_batch / setup_conditioning unchanged; tools/ref_env.py supplies the Lightning / Hydra
                     stand-ins): stage-1 inputs -> encode -> conditioning -> 5 Euler updates -> decode, with the initial noise fixed
@@ -526,7 +527,77 @@ def f10():
     npz("f10_linear_attention.npz", **arrays)
 
 
+# ------------------------------------------------------------------------------------------- F11
+def f11():
+    """The conditioned caller, REAL files: second_stage/pedestrian.py CondWrapper built by its own __init__ from the reference YAMLs;
+    `CondWrapper.prepare_batch` (:242-251: y = Embedding(cond_scene)) and the K = 20 `test_step` loop (:186-212: K sequential sample()
+    calls, future frames, real agents only, best-of-K ADE / FDE) executed UNCHANGED, each sample() drawing its initial state from a stored
+    noise.  Backbone weights = oracle.random_params(seed) loaded into the reference module (only the seed is stored)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_env
+    from lam_slide_amd import dropin
+    dropin.uninstall()
+    ns = ref_env.setup()
+    F = ref_env.F11
+    B, T, A, L, K = F["B"], F["T"], F["A"], F["L"], F["K"]
+    lift = torch.randn(3, 128, generator=torch.Generator().manual_seed(30)) * 0.5
+    first, first_cls = ref_env.build_first_stage(ns, seed=31, num_latents=L, lift=lift)
+    w = ref_env.build_pedestrian_wrapper(ns, first, first_cls)
+    w.eval()
+    sh = latent_net.NetShape(**F["backbone"])
+    wseed = 34
+    w.backbone.load_state_dict(latent_net.random_params(sh, seed=wseed))
+    batch = ref_env.f11_batch()
+    g = torch.Generator().manual_seed(35)
+    batch["pos"] = torch.randn(B, T, A, 3, generator=g)  # positions; the first stage lifts them (ref_env.build_first_stage)
+    true_future = batch["pos"][:, F["cond_idx"][1]:].clone()
+    noises = torch.randn(K, B, T, L, 32, generator=g)
+    # prepare_batch on its own (the conditioning the sampler receives)
+    pb = w.prepare_batch({k: v.clone() for k, v in batch.items()})
+    y, xc, mask, lat = pb["model_kwargs"]["y"], pb["model_kwargs"]["x_cond"], pb["model_kwargs"]["x_cond_mask"], pb["x1"]
+    assert torch.equal(y, w.vec_in_embedding.weight[batch["cond_scene"]])
+    # the K-sample evaluation loop
+    finals, poss = [], []
+    real_decode = w.decode
+
+    def tap(latents, entities):
+        # As committed, the reference's test_step cannot run on its own decode(): decode() returns positions as [B, T, A, D]
+        # (pedestrian.py:140-143, nba.py:145-148) and test_step rearranges "(B T) L D -> B T L D" again (pedestrian.py:194, nba.py:207),
+        # which einops refuses for a 4-D tensor.  The loop is executed unchanged around a decode() that hands it the layout it asks for.
+        out = real_decode(latents, entities)
+        finals.append(latents.clone().reshape(B, T, L, 32))
+        poss.append(out["pos"].clone())
+        return {"pos": out["pos"].reshape(B * T, A, -1)}
+
+    w.decode = tap
+    w.on_test_epoch_start()
+    tb = {k: v.clone() for k, v in batch.items()}
+    with ref_env.randn_like_sequence(noises) as seq:
+        w.test_step(tb, 0)
+    assert seq.i == K and len(finals) == K
+    ades, fdes = torch.cat(w.test_step_outputs["eth"]["ades"]), torch.cat(w.test_step_outputs["eth"]["fdes"])
+    finals, poss = torch.stack(finals), torch.stack(poss)  # [K,B,T,L,32], [K,B,T,A,3]
+    # the oracle chain on the same inputs
+    s1 = {k: v.clone() for k, v in first.backbone.state_dict().items()}
+    sd = latent_net.random_params(sh, seed=wseed)
+    flat = lambda t: t.reshape(B * T, *t.shape[2:])  # noqa: E731
+    zeroed = batch["pos"].clone()
+    zeroed[:, F["cond_idx"][1]:] = 0  # (test_step zeroes the future frames before sampling: pedestrian.py:175-176)
+    o_lat = harness.encode(s1, harness.EncoderShape(num_latents=L), flat(zeroed @ lift), flat(batch["entities"]), flat(batch["attention_mask"])).reshape(B, T, L, 32)
+    oxc, omask = harness.setup_conditioning(o_lat, tuple(F["cond_idx"]), True)
+    o_final = torch.stack([harness.sample_latents(sd, sh, otr.Transport("GVP", "data"), noises[k], oxc, omask, y, "ODE",
+                                                  {"sampling_method": "euler", "num_steps": F["num_steps"]}) for k in range(K)])
+    o_pos = harness.decode(s1, harness.DecoderShape(), o_final.reshape(K * B * T, L, 32), flat(batch["entities"]).repeat(K, 1)).reshape(poss.shape)
+    print(f"F11 real pedestrian CondWrapper: conditioning {rel(oxc[:, :F['cond_idx'][1]], xc[:, :F['cond_idx'][1]]):.2e} finals {rel(o_final, finals):.2e} positions {rel(o_pos, poss):.2e}; "
+          f"ADE {ades.mean():.4f} FDE {fdes.mean():.4f} over {ades.numel()} agents")
+    assert rel(o_final, finals) < 1e-5 and rel(o_pos, poss) < 1e-5 and torch.equal(omask, mask)
+    npz("f11_pedestrian_k.npz", stage1=s1, lift=lift, weight_seed=np.array(wseed), embedding=w.vec_in_embedding.weight.detach().clone(),
+        pos=batch["pos"], entities=batch["entities"], attention_mask=batch["attention_mask"], cond_scene=batch["cond_scene"], noises=noises,
+        y=y, x_cond=xc, mask=mask, finals=finals, positions=poss, ades=ades, fdes=fdes, true_future=true_future,
+        meta=np.array([B, T, A, L, K, F["cond_idx"][0], F["cond_idx"][1], F["num_steps"]]), shape=shape_dict(sh))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
     for w in which:
         globals()[w]()

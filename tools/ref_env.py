@@ -11,12 +11,14 @@ stand-ins that let those files import:
     omegaconf.DictConfig           = AttrDict (dict with attribute access)
     torchmetrics.MeanMetric        an nn.Module that is never updated here
     torchdiffeq.odeint             fixed-grid Euler with the package's published semantics (grid == t, states stacked; method == "euler")
+    torch_kmeans.KMeans            a name only (second_stage/pedestrian.py imports it; used only with post_process=True, which no config sets)
+    src.datasets.pedestrian        only ``dataset_cond_indices`` (the five scene names; the real module imports the dataset stack)
     src.utils (package shell)      real ``pylogger`` / ``tensor_utils`` are imported from the reference, ``__init__`` is not executed;
                                    ``src.utils.utils.load_class`` is the reference's four lines of importlib (checkpoint plumbing)
     src.datasets.md17              only ``dataset_cond_indices`` (a dict of 8 molecule names; the real module imports the dataset stack)
     lightning_utilities.core.rank_zero   the two names pylogger imports
 
-Used by ``tools/make_fixtures.py f9`` and by ``tests/test_dropin.py`` (skipped where /root/reference does not exist).  Nothing here ships.
+Used by ``tools/make_fixtures.py f9 f11`` and by ``tests/test_dropin.py`` (skipped where /root/reference does not exist).  Nothing here ships.
 """
 from __future__ import annotations
 
@@ -147,6 +149,13 @@ def setup():
             return torch.stack(ys)
 
         mod("torchdiffeq", odeint=odeint)
+
+        class KMeans:  # (second_stage/pedestrian.py:8; instantiated only under post_process=True)
+            def __init__(self, *a, **k):
+                raise RuntimeError("torch_kmeans is not available in the build container (post_process=True is not covered)")
+
+        mod("torch_kmeans", KMeans=KMeans)
+        mod("src.datasets.pedestrian", dataset_cond_indices={"zara1": 0, "zara2": 1, "univ": 2, "hotel": 3, "eth": 4})  # (datasets/pedestrian.py:14-20)
         rz = lambda fn: fn  # noqa: E731
         rz.rank = 0
         mod("lightning_utilities", core=mod("lightning_utilities.core", rank_zero=mod(
@@ -183,7 +192,7 @@ F9 = dict(B=2, T=6, A=5, L=16, dim_input=128, dim_latent=32, n_entities=32, cond
 _STAGE1 = {}
 
 
-def build_first_stage(ns, seed=21):
+def build_first_stage(ns, seed=21, num_latents=None, lift=None):
     """FirstStageLightningBase (real class) around a BackboneBase (real class) with the real Encoder / Decoder; `prepare_inputs` - the
     first stage's atom / position embedding, not on this path - hands through batch["pos"], which the F9 inputs carry already merged."""
     from functools import partial
@@ -191,7 +200,7 @@ def build_first_stage(ns, seed=21):
     torch.manual_seed(seed)
     emb = ns.entity.EntityEmbeddingOrthogonal(n_entiy_embeddings=F9["n_entities"], embedding_dim=128, max_norm=1)
     act = partial(ns.torch_modules.GELU)
-    enc = ns.encoder.Encoder(dim_input=F9["dim_input"], dim_latent=F9["dim_latent"], dim_head_cross=16, dim_head_latent=16, num_latents=F9["L"],
+    enc = ns.encoder.Encoder(dim_input=F9["dim_input"], dim_latent=F9["dim_latent"], dim_head_cross=16, dim_head_latent=16, num_latents=num_latents or F9["L"],
                              num_head_cross=8, num_head_latent=2, num_block_cross=1, num_block_attn=1, qk_norm=True, entity_embedding=emb, act=act)
     dec = ns.decoder.Decoder(outputs={"pos": 3}, dim_query=128, dim_latent=F9["dim_latent"], entity_embedding=emb, dim_head_cross=16,
                              dim_head_latent=16, num_head_cross=8, num_head_latent=2, num_block_cross=0, num_block_attn=1, dropout_query=0.1,
@@ -200,8 +209,8 @@ def build_first_stage(ns, seed=21):
         emb.embedding.weight.mul_(torch.linspace(0.5, 1.8, F9["n_entities"])[:, None])  # some rows above unit norm: the max_norm path
 
     class Backbone(lb.BackboneBase):
-        def prepare_inputs(self, batch):
-            return batch["pos"]
+        def prepare_inputs(self, batch):  # (F11: positions [.., 3] lifted to the encoder's input width by a fixed matrix stored in the fixture)
+            return batch["pos"] if lift is None else batch["pos"] @ lift
 
     class FirstStage(lb.FirstStageLightningBase):
         def __init__(self, backbone):
@@ -255,6 +264,70 @@ class fixed_randn_like:
     def __enter__(self):
         self._orig = torch.randn_like
         torch.randn_like = lambda x, **kw: self.noise.to(x.dtype).clone()
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self._orig
+
+
+# ---- F11: the reference's real pedestrian CondWrapper (second_stage/pedestrian.py), its prepare_batch and its K-sample test_step ----
+
+F11 = dict(B=3, T=20, A=4, L=2, K=20, cond_idx=[0, 8], num_steps=11, n_classes=5, vec_in_dim=256,
+           backbone=dict(depth=2, in_dim=32, hidden_size=128, mlp_ratio=2, num_heads=4, normalize=True, vec_in_dim=256))
+
+
+def build_pedestrian_wrapper(ns, first_stage, first_stage_cls, seed=32):
+    """second_stage/pedestrian.py CondWrapper, constructed by ITS OWN __init__ from the reference's own YAML blocks
+    (configs/model/pedestrian/second-stage.yaml + second-stage_cond.yaml) with the F11 sizes (true T = 20, L = 2; depth 2 instead of 6)."""
+    import yaml
+    ped = importlib.import_module("src.models.composites.second_stage.pedestrian")
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs/model/pedestrian/second-stage.yaml")))
+    cond = yaml.safe_load(open(os.path.join(REF, "configs/model/pedestrian/second-stage_cond.yaml")))
+    for k in ("_target_", "_recursive_", "defaults"):
+        cfg.pop(k, None)
+    assert cond["_target_"].endswith("pedestrian.CondWrapper") and cfg["K"] == 20 and cfg["num_runs"] == 20 and cfg["cond_idx"] == F11["cond_idx"]
+    cfg.update(compile=False, num_timesteps=F11["T"], ema=None, scheduler=None, n_classes=cond["n_classes"], vec_in_dim=cond["vec_in_dim"],
+               sampling_method="ODE", sampling_kwargs={"sampling_method": "euler", "num_steps": F11["num_steps"]})
+    bb = {k: v for k, v in cfg["backbone"].items() if k != "n_timesteps"}
+    cfg["backbone"] = dict(bb, n_timesteps=F11["T"], **F11["backbone"])
+    key = f"f11-stage1-{id(first_stage)}"
+    _STAGE1[key] = first_stage
+    mod_name = "_lsl_f11_first_stage"
+    sys.modules.setdefault(mod_name, types.ModuleType(mod_name)).FirstStage = first_stage_cls
+    cfg["first_stage_model"] = {"class_name": f"{mod_name}.FirstStage", "path": key}
+    torch.manual_seed(seed)
+    w = ped.CondWrapper(**{k: (AttrDict(v) if isinstance(v, dict) else v) for k, v in cfg.items()})
+    # what Lightning provides around test_step: the datamodule's name of the dataloader (second_stage/pedestrian.py:162)
+    w.trainer = types.SimpleNamespace(datamodule=types.SimpleNamespace(dataloader_names=lambda idx: "eth"))
+    return w
+
+
+def f11_batch(seed=33):
+    g = torch.Generator().manual_seed(seed)
+    B, T, A = F11["B"], F11["T"], F11["A"]
+    am = torch.ones(B, T, A, dtype=torch.bool)
+    am[1, :, 3] = False  # a padded agent: its rows are dropped from the error statistics (pedestrian.py:171-173)
+    am[2, :, 2:] = False
+    return {"pos": torch.randn(B, T, A, F9["dim_input"], generator=g),
+            "entities": torch.stack([torch.randperm(F9["n_entities"], generator=g)[:A] for _ in range(B)])[:, None].expand(B, T, A).contiguous(),
+            "attention_mask": am, "cond_scene": torch.tensor([4, 0, 2])}
+
+
+class randn_like_sequence:
+    """Context manager: the i-th torch.randn_like call returns noises[i] (one initial state per sample() call of the K-loop)."""
+
+    def __init__(self, noises):
+        self.noises, self.i = noises, 0
+
+    def __enter__(self):
+        self._orig = torch.randn_like
+
+        def fake(x, **kw):
+            out = self.noises[self.i].to(x.dtype).clone()
+            self.i += 1
+            return out
+
+        torch.randn_like = fake
         return self
 
     def __exit__(self, *exc):
