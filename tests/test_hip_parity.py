@@ -375,6 +375,28 @@ def test_batch_independence_and_chunking_bit_exact(dev):
     assert torch.isfinite(full).all()
 
 
+def test_batch_independence_across_the_linear2_tiling_threshold_384(dev):
+    """384-wide models (peptide family: linear2 K = 2 048 has no weight-stationary instance): linear2 runs the 192 x 128 tiling from about
+    8 192 tokens per pass (host_launch.hip.h, gemm_variant 28) and the 128 x 128 one below.  The two must be bit-identical - "a trajectory's
+    bits are the same in any batch" rests on it here: trajectory k of a 6-trajectory call (12 000 tokens: tiling 28) against the same
+    trajectory sampled alone (2 000 tokens: tiling 11), and against passes of 2 (4 000 tokens)."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler
+    from oracle import latent_net
+    sh = latent_net.NetShape(depth=2, in_dim=96, hidden_size=384, num_heads=16, mlp_ratio=4)
+    net = build_net(sh, latent_net.random_params(sh, seed=13), dev)
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(6, 1000, 2, 96, generator=g).to(dev)
+    init = torch.randn(6, 1000, 2, 96, generator=g).to(dev)
+    drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, 1), sampling_kwargs={"sampling_method": "euler", "num_steps": 3})
+    full = drv.sample_latents(lat, init=init)
+    for k in (0, 5):
+        assert torch.equal(full[k:k + 1], drv.sample_latents(lat[k:k + 1], init=init[k:k + 1])), f"trajectory {k}: alone vs in the batch of 6"
+    net.set_chunk(2)
+    assert torch.equal(full, drv.sample_latents(lat, init=init)), "passes of 2 trajectories"
+    net.set_chunk(0)
+    assert torch.isfinite(full).all()
+
+
 def test_pass_size_rule_equal_passes_under_the_token_cap(dev):
     """lsl_pass_size: a pass holds at most 256 Ki tokens, and a batch that needs several passes is cut into EQUAL ones (1024 trajectories of
     640 tokens: 342 + 342 + 340, not 409 + 409 + 206 - the short pass fills the chip worse); results do not depend on it (test above)."""
