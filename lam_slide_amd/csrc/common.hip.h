@@ -114,10 +114,11 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 // erf-GELU of TWO accumulator values, rounded to one packed bf16 pair, with the polynomial and the final fma on the packed-fp32 pipe
-// (v_pk_fma_f32: 6 instead of 12 FMAs per pair; 13 vector instructions per pair where two gelu_fast calls + a pack take 21).  Same
-// polynomial and operation order per element as gelu_fast: the same values.  ASM_MAX: max(x, 0) as one inline-asm v_max_f32 (see
-// lin1_gelu, k_lin1.hip.h): only for values the matrix pipe finished writing long ago - inline asm is invisible to the hazard recognizer.
-template <bool ASM_MAX>
+// (v_pk_fma_f32: 6 instead of 12 FMAs per pair) and max(x, 0) as ONE integer maximum per value (v_max_i32 on the bit pattern: positive
+// floats are positive integers, negative floats negative ones; the fp32 maximum costs hipcc a canonicalising v_max first, and an inline-asm
+// v_max_f32 is invisible to the hazard recognizer right behind the MFMA that wrote x): 13 vector instructions per pair where two
+// gelu_fast calls + a pack take 21.  Same polynomial and operation order per element as gelu_fast: the same values, except that a
+// negative NaN gives 0 instead of NaN.
 __device__ __forceinline__ unsigned gelu_pair_bf16(float x0, float x1) {
     const f32x2 x = {x0, x1};
     const f32x2 ax = __builtin_elementwise_abs(x);
@@ -128,13 +129,7 @@ __device__ __forceinline__ unsigned gelu_pair_bf16(float x0, float x1) {
     q = __builtin_elementwise_fma(q, ax, f32x2{-1.1507878303527832f, -1.1507878303527832f});
     q = __builtin_elementwise_fma(q, ax, f32x2{-1.000037670135498f, -1.000037670135498f});
     const f32x2 h = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
-    f32x2 relu;
-    if (ASM_MAX) {
-        asm("v_max_f32 %0, 0, %1" : "=v"(relu[0]) : "v"(x0));
-        asm("v_max_f32 %0, 0, %1" : "=v"(relu[1]) : "v"(x1));
-    } else {
-        relu = f32x2{__builtin_amdgcn_fmed3f(x0, 0.0f, __builtin_inff()), __builtin_amdgcn_fmed3f(x1, 0.0f, __builtin_inff())};
-    }
+    const f32x2 relu = {__int_as_float(max(__float_as_int(x0), 0)), __int_as_float(max(__float_as_int(x1), 0))};
     const f32x2 r = __builtin_elementwise_fma(-ax, h, relu);
     return __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }

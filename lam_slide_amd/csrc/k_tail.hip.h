@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
             // GELU(j): 16 values per lane, rounded to bf16 = the two B fragments of D(j) (accumulator registers 8 s .. 8 s + 7 are k-step s)
             u32x4 gw[2];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) gw[s >> 2][s & 3] = gelu_pair_bf16<false>(up[2 * s], up[2 * s + 1]);
+            for (int s = 0; s < 8; ++s) gw[s >> 2][s & 3] = gelu_pair_bf16(up[2 * s], up[2 * s + 1]);
             __builtin_amdgcn_sched_barrier(0);
             // D(j).  In front of the tile's last one: the h rows of the first NPF feature tiles are requested, behind the registers of the
             // activations (dead now), so that they arrive under the chain.  Rows beyond N are read (h is padded to whole 256-row tiles), never written.
