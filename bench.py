@@ -72,8 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--updates", type=int, default=0, help="profiling only: state updates per sampling call instead of the workload's (the line is marked "
                                                            "config.reduced_updates; never a headline number).  PMC passes of the 1000-step peptide call need it")
     ap.add_argument("--tail", default="auto", choices=("auto", "on", "off"),
-                    help="sub-block decomposition of the model handle (lam_slide_amd.LatentSIV3.set_tail): auto = the tail form for the NBA family "
-                         "at >= 131 072 tokens per GPU (where it is faster), the default form elsewhere")
+                    help="sub-block decomposition of the model handle (lam_slide_amd.LatentSIV3.set_tail): auto = the tail form for hidden-256 "
+                         "models (NBA, md17_ref) at >= 131 072 tokens per GPU (where it is faster), the default form elsewhere")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch and stage-1 legs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event passes (rocprofv3 runs: every launch of the trace then belongs to a warm-up or timed sampling call)")
@@ -255,7 +255,7 @@ def run_rank(args) -> int:
         if args.chunk:
             net.set_chunk(args.chunk)
         # the caller's choice of decomposition, made per MODEL OBJECT (never per call): large NBA batches take the tail form
-        tail_on = args.tail == "on" or (args.tail == "auto" and args.workload == "nba" and B * T * L >= 131072)
+        tail_on = args.tail == "on" or (args.tail == "auto" and kw["hidden_size"] == 256 and B * T * L >= 131072)
         if tail_on or args.tail == "off":
             net.set_tail(tail_on)
         tr = CreateTransport("GVP", "data")()
