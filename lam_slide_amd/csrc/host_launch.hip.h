@@ -256,7 +256,7 @@ int tail_env() {
     return v;
 }
 bool tail_shape_ok(int D, int HHD, int M) {
-    return tail_env() != 0 && D == 256 && HHD == 256 && M % 32 == 0 && M >= 64 && TailCfg<256, 256>::lds_bytes(M) <= (size_t)163840;
+    return tail_env() != 0 && D == 256 && HHD == 256 && M % 64 == 0 && M >= 64 && TailCfg<256, 256>::lds_bytes(M) <= (size_t)163840;  // (an even number of 32-feature mlp blocks: the kernel's pipeline has no parity branches)
 }
 size_t tail_stream_bytes(const lsl_model *m) { return TailCfg<256, 256>::stream_bytes(m->d.mlp_dim); }
 void launch_tail(const TailArgs &a, hipStream_t st) {

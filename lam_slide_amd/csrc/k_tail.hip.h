@@ -12,19 +12,23 @@
 // rows for a whole tile: the mlp activations never leave the registers, h is read and written once, and the row statistics are wave-local.
 //
 // Structure (the token-stationary form of k_lin1.hip.h, with a second GEMM fed from the accumulators of the first):
-//   * a workgroup = NW waves x 32 tokens; wave w keeps its tokens' activations `a` (D / 4 VGPRs) as the MFMA B fragments of every k-step and
-//     the whole output tile out^T[D features][32 tokens] (D / 2 accumulator VGPRs): NW = 8 (two waves per SIMD) for D <= 256, NW = 4 (one wave
-//     per SIMD, the 512-register file) above;
+//   * a workgroup = 8 waves x 32 tokens (two waves per SIMD, hidden <= 256); a wave keeps the whole output tile out^T[D features][32 tokens]
+//     (D / 2 accumulator VGPRs) and the first half of its tokens' activations `a` as MFMA B fragments in registers (D / 8 VGPRs); the other
+//     half lives as lane-linear 1 KiB fragments in 8 KiB of wave-private LDS (whose first 4 KiB double as the staging image outside the
+//     mlp phase): the registers that frees hold a second accumulator tile and a second packed fragment - the software pipeline below;
 //   * the WEIGHTS stream through LDS as ONE linear sequence of 1 KiB MFMA A fragments, packed once per call in exactly the order the kernel
 //     consumes them (k_tail_pack): chunks of D / 16 fragments = [Wo k-steps 2c, 2c+1 x all D/32 output tiles] for the attention half,
 //     then per mlp block j of 32 features [W1m block j: D/16 k-steps] and [W2m columns of block j: D/32 output tiles x 2 k-steps], in the
-//     order U(0) U(1) D(0) U(2) D(1) ... U(MB-1) D(MB-2) D(MB-1).  A ring of NS chunks filled by LDS-DMA NS - 1 chunks ahead, one counted
-//     wait + one workgroup barrier per chunk; the sequence is cyclic, so the ring runs through tile boundaries;
-//   * up-projection U(j): D/16 MFMAs into one 32 x 32 accumulator tile (bias as the initial value) while the erf-GELU of block j - 1 (the
-//     other accumulator tile) is computed in their shadows, 2 values per eighth of the chain; its 16 values per lane, rounded to bf16, ARE
-//     the B fragments of the down-projection D(j - 1) - accumulator registers 8 s .. 8 s + 7 of a lane are k-step s - with W2m's columns
-//     permuted to the accumulator's row order by the packer (the P-from-accumulator form of k_attn.hip.h);
-//   * epilogue per tile and wave, through 4 KiB of wave-private LDS: the h rows arrive row-wise (whole 128-byte segments, 8 rows per
+//     order U(0) U(1) D(0) U(2) D(1) ... U(MB-1) D(MB-2) D(MB-1).  A ring of 4 chunks = two PAIRS filled by LDS-DMA one pair ahead, one wait
+//     + one workgroup barrier per pair (at one per chunk the barrier's drain left the matrix pipe idle for a third of a step); the
+//     sequence is cyclic, so the ring runs through tile boundaries;
+//   * up-projection U(j): D/16 MFMAs into one 32 x 32 accumulator tile (bias as the initial value; blocks alternate between two tiles); its
+//     16 values per lane, erf-GELU'd and rounded to bf16, ARE the B fragments of the down-projection D(j) - accumulator registers 8 s ..
+//     8 s + 7 of a lane are k-step s - with W2m's columns permuted to the accumulator's row order by the packer (the P-from-accumulator
+//     form of k_attn.hip.h).  The GELU of block j runs in the MFMA shadows of THIS wave's D(j - 1) and U(j + 1), one pair of values behind
+//     every fourth MFMA: a wave's vector instructions overlap only with its own MFMAs - beside its SIMD partner's MFMA chain they advance
+//     at 9 % of their rate (tools/microbench_coissue.hip, profiles/r06_experiments.txt section 5);
+//   * epilogue per tile and wave, through the 4 KiB staging image: the h rows arrive row-wise (whole 128-byte segments, 8 rows per
 //     instruction), are re-read in the accumulator layout, updated, summed; the updated rows leave the same way; then the second pass over
 //     the registers writes a_next.  Amortised over >= 1 000 MFMAs per wave.
 //
@@ -54,26 +58,29 @@ struct TailArgs {
 template <int D, int HHD>
 struct TailCfg {
     static_assert(D % 64 == 0 && D <= 256 && HHD % 64 == 0, "hidden sizes 64 .. 256 (the output tile of a wave is D / 2 accumulator registers)");
-    static constexpr int NW = 8;            // waves per workgroup: two per SIMD, waves w and w + 4 share one
+    static constexpr int NW = 8;            // waves per workgroup: two per SIMD
     static constexpr int NT = D / 32;       // output tiles of 32 features
-    static constexpr int KS = D / 16;       // k-steps of the up-projection = B fragments a wave keeps
+    static constexpr int KS = D / 16;       // k-steps of the up-projection
+    static constexpr int KR = KS / 2;       // ... of which the first KR stay in registers as B fragments, the rest in the wave's LDS image
     static constexpr int KZ = HHD / 16;     // k-steps of the attention half
     static constexpr int CHF = D / 16;      // fragments per chunk
     static constexpr int CH = CHF * 1024;   // bytes per chunk
     static constexpr int CO = HHD / 32;     // chunks of the attention half
-    static constexpr int NS = 6;            // ring slots = three PAIRS of chunks: the leading half's pair, the trailing half's older chunk, the pair in flight
+    static constexpr int NS = 4;            // ring slots = two PAIRS of chunks: one pair in use, the next in flight
     static constexpr int PPW = CHF / NW;    // DMA instructions per wave and chunk
     static_assert(CHF % NW == 0, "whole DMA instructions per wave");
-    static constexpr int RING = NS * CH, STAGE = NW * 4096;
-    static constexpr size_t lds_bytes(int M) { return (size_t)RING + STAGE + (size_t)M * 4; }
+    static constexpr int AIMG = (KS - KR) * 1024 < 4096 ? 4096 : (KS - KR) * 1024;  // per wave: activation fragments KR .. KS - 1; its first 4 KiB double as the staging image
+    static constexpr int RING = NS * CH, WAVE = NW * AIMG;
+    static constexpr size_t lds_bytes(int M) { return (size_t)RING + WAVE + (size_t)M * 4; }
     static size_t stream_bytes(int M) { return (size_t)(CO + 2 * (M / 32)) * CH; }
 };
 
 // Weight stream of one sub-block.  16-byte piece i = lane (r = lane & 31, hf = lane >> 5) of fragment f of chunk c:
-//   c < CO         Wo:   fragment f = 2 ft + s -> W2[32 ft + r][32 c + 16 s + 8 hf + 0..7]
-//   c = CO + 2 j   U(j): fragment ks -> W1[3 HHD + 32 j + r][16 ks + 8 hf + 0..7]
-//   c = CO + 2 j+1 D(j): fragment f = 2 ft + s -> W2[32 ft + r][HHD + 32 j + phi(s, hf, 0..7)],  phi = 16 s + 8 (i >> 2) + 4 hf + (i & 3):
-//                  the mlp feature whose GELU sits in accumulator register 8 s + i of a lane of half hf (common.hip.h: mfma32 C/D map)
+//   c < CO                      Wo:  fragment f = 2 ft + s -> W2[32 ft + r][32 c + 16 s + 8 hf + 0..7]
+//   then e = c - CO: e = 0 U(0); odd e < 2 MB - 1: U((e + 1) / 2); even e: D(e / 2 - 1); e = 2 MB - 1: D(MB - 1)
+//   U(j): fragment ks -> W1[3 HHD + 32 j + r][16 ks + 8 hf + 0..7]
+//   D(j): fragment f = 2 ft + s -> W2[32 ft + r][HHD + 32 j + phi(s, hf, 0..7)],  phi = 16 s + 8 (i >> 2) + 4 hf + (i & 3):
+//         the mlp feature whose GELU sits in accumulator register 8 s + i of a lane of half hf (common.hip.h: mfma32 C/D map)
 __global__ void __launch_bounds__(256) k_tail_pack(u16 *out, const u16 *W1, const u16 *W2, int D, int HHD, int M) {
     const int CHF = D / 16, CO = HHD / 32, MB = M / 32, K2 = HHD + M;
     const long total = (long)(CO + 2 * MB) * CHF * 64;
@@ -86,10 +93,13 @@ __global__ void __launch_bounds__(256) k_tail_pack(u16 *out, const u16 *W1, cons
             const int ft = f >> 1, s = f & 1;
             v = *reinterpret_cast<const u32x4 *>(W2 + (size_t)(32 * ft + r) * K2 + 32 * c + 16 * s + 8 * hf);
         } else {
-            const int e = c - CO, j = e >> 1;
-            if ((e & 1) == 0) {
+            const int e = c - CO;
+            const bool up = e == 0 || ((e & 1) && e < 2 * MB - 1);
+            if (up) {
+                const int j = e == 0 ? 0 : (e + 1) >> 1;
                 v = *reinterpret_cast<const u32x4 *>(W1 + (size_t)(3 * HHD + 32 * j + r) * D + 16 * f + 8 * hf);
             } else {
+                const int j = e == 2 * MB - 1 ? MB - 1 : (e >> 1) - 1;
                 const int ft = f >> 1, s = f & 1;
                 const u16 *src = W2 + (size_t)(32 * ft + r) * K2 + HHD + 32 * j + 16 * s + 4 * hf;
                 const u32x2 lo = *reinterpret_cast<const u32x2 *>(src), hi = *reinterpret_cast<const u32x2 *>(src + 8);
@@ -103,19 +113,18 @@ __global__ void __launch_bounds__(256) k_tail_pack(u16 *out, const u16 *W1, cons
 template <int D, int HHD>
 __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
     using C = TailCfg<D, HHD>;
-    constexpr int NW = C::NW, NT = C::NT, KS = C::KS, KZ = C::KZ, CHF = C::CHF, CH = C::CH, CO = C::CO, NS = C::NS, PPW = C::PPW;
+    constexpr int NW = C::NW, NT = C::NT, KS = C::KS, KR = C::KR, KZ = C::KZ, CHF = C::CHF, CH = C::CH, CO = C::CO, NS = C::NS, PPW = C::PPW;
     constexpr int PD = 2;  // A fragments requested this many MFMAs ahead
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char *const stage = smem + C::RING + wave * 4096;
-    float *const b1_lds = reinterpret_cast<float *>(smem + C::RING + C::STAGE);
+    char *const aimg = smem + C::RING + wave * C::AIMG;  // this wave's activation fragments KR .. KS - 1; [0, 4 KiB) = its staging image outside the mlp phase
+    float *const b1_lds = reinterpret_cast<float *>(smem + C::RING + C::WAVE);
 
     // Work = wave tiles of 32 tokens, cut evenly over the workgroups; a workgroup walks its range in rounds of NW wave tiles (one per wave).  In
-    // a last, partial round the waves without a tile only keep the ring going: with one active wave per SIMD the round is bound by half the
-    // MFMA work, so 2.5 rounds of work take about 2.6 round times, not 3.
-    const int MB = g.M >> 5, NPAIR = (CO + 2 * MB) >> 1;
+    // a last, partial round the waves without a tile only keep the ring going.
+    const int MB = g.M >> 5, NPAIR = (CO + 2 * MB) >> 1;  // (M is a multiple of 64: MB even)
     const int nwt = (g.N + 31) >> 5;
     const int w0 = (int)((long)nwt * blockIdx.x / gridDim.x), w1 = (int)((long)nwt * (blockIdx.x + 1) / gridDim.x);
     if (w0 >= w1) return;  // (uniform)
@@ -124,15 +133,15 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
     for (int i = tid * 4; i < g.M; i += NW * 64 * 4) *reinterpret_cast<float4 *>(b1_lds + i) = *reinterpret_cast<const float4 *>(g.b1 + i);
 
     // Everything a phase needs per lane (row / chunk indices, staging addresses, row pointers, fragment bases) is derived from a lane id that
-    // is laundered INSIDE that phase: hipcc cannot hoist those values out of the round loop, where - with the output tile and the activations
-    // resident - they would live in scratch, and a scratch reload inside the chunk loop is a vector-memory operation whose wait also waits
-    // for the ring requests just issued.
+    // is laundered INSIDE that phase: hipcc cannot hoist those values out of the round loop, where - with the output tile, the activations and
+    // two accumulator tiles resident - they would live in scratch, and a scratch reload inside the chunk loop is a vector-memory operation
+    // whose wait also waits for the ring requests just issued.
     auto fresh_lane = [&]() __attribute__((always_inline)) {
         int l = lane;
         asm volatile("" : "+v"(l));
         return l;
     };
-    // ---- weight ring: the stream's chunk k -> slot k mod 6; wave w requests fragments PPW w .. PPW w + PPW - 1 of a chunk, one LDS-DMA
+    // ---- weight ring: the stream's chunk k -> slot k mod 4; wave w requests fragments PPW w .. PPW w + PPW - 1 of a chunk, one LDS-DMA
     // instruction each (inline asm on purpose, k_lin1.hip.h: behind the builtin hipcc waits for the request in front of the next LDS access)
     const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))(smem);
     const char *const w_base = reinterpret_cast<const char *>(g.wt) + (size_t)wave * PPW * 1024;
@@ -141,7 +150,7 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
         const unsigned ls = (unsigned)fresh_lane() * 16u;
         asm volatile("s_add_u32 m0, %2, 0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(ls), "s"(src), "s"(dst), "n"(1024 * I) : "memory", "scc");
     };
-    int p_src = 0, slot_d = 0;  // next PAIR of the stream to request (index in [0, NPAIR)), and its first slot (0, 2 or 4)
+    int p_src = 0, slot_d = 0;  // next PAIR of the stream to request (index in [0, NPAIR)), and its first slot (0 or 2)
     auto issue_pair = [&]() __attribute__((always_inline)) {
         const char *src = w_base + (size_t)p_src * (2 * CH);
         const unsigned dst = lds0 + slot_d * CH + wave * PPW * 1024;
@@ -150,39 +159,30 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
         issue_piece(src + CH, dst + CH, std::integral_constant<int, 0>());
         if constexpr (PPW > 1) issue_piece(src + CH, dst + CH, std::integral_constant<int, 1>());
         p_src = p_src + 1 == NPAIR ? 0 : p_src + 1;
-        slot_d = slot_d == NS - 2 ? 0 : slot_d + 2;
+        slot_d ^= 2;
     };
     static_assert(PPW <= 2, "D <= 256");
     int slot_c = 0;  // slot of the next chunk this wave computes
-    // Barrier p of the workgroup (one wait + one barrier per PAIR of chunks: at one per chunk the barrier's drain - every wave stops, requests
-    // and restarts its fragment reads at the same moment - left the matrix pipe idle for a third of a step, measured).  The pair (2p, 2p + 1)
-    // has landed: requested a whole pair ago (EXTRA = vector-memory operations the wave has issued since, which may stay in flight).  Behind it
-    // the LEADING half (waves 0-3) computes chunks 2p, 2p + 1, the TRAILING half (waves 4-7: the SIMD partners) 2p - 1, 2p: one chunk behind,
-    // so that one wave's GELU (vector pipe) always runs beside its partner's MFMA chain and the two down- / up-projection chains of a SIMD
-    // never coincide with two GELUs.  Nobody reads chunks <= 2p - 2 any more: the pair (2p + 2, 2p + 3) is requested into their slots.
+    // Head of a PAIR of chunks: one wait + one workgroup barrier per 2 CHF MFMAs of a wave.  Both chunks were requested a whole pair ago (EXTRA =
+    // vector-memory operations the wave has issued since, which may stay in flight); every wave has left the previous pair, whose two slots
+    // take the next pair's requests.
     auto pair_head = [&](auto extra_c) __attribute__((always_inline)) {
         wait_vmcnt<decltype(extra_c)::value>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue_pair();
     };
-    auto next_slot = [&]() __attribute__((always_inline)) { slot_c = slot_c == NS - 1 ? 0 : slot_c + 1; };
+    auto next_slot = [&]() __attribute__((always_inline)) { slot_c = (slot_c + 1) & (NS - 1); };
     auto frag = [&](const char *sb, int f) __attribute__((always_inline)) { return as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + f * 1024)); };
 
     std::integral_constant<int, 0> E0;
-#ifdef TAIL_STAGGER
-    {   // harness experiment: workgroups start in TAIL_STAGGER phase groups, TAIL_STAGGER_SLEEPS x ~4 us apart
-        const int ph = (blockIdx.x >> 3) % TAIL_STAGGER;
-        for (int k = 0; k < ph * TAIL_STAGGER_SLEEPS; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     issue_pair();
     __syncthreads();  // bias table
 
-    const unsigned st0 = (unsigned)(size_t)(LDS_PTR(char))(stage);
-    const unsigned b1_base = (unsigned)(size_t)(LDS_PTR(char))(smem + C::RING + C::STAGE);  // (uniform)
+    const unsigned st0 = (unsigned)(size_t)(LDS_PTR(char))(aimg);
+    const unsigned b1_base = (unsigned)(size_t)(LDS_PTR(char))(smem + C::RING + C::WAVE);  // (uniform)
     // rows of a [tokens][K] bf16 matrix as MFMA B fragments (k_lin1.hip.h load_x / finish_x): whole 128-byte lines per 8 lanes (8 rows per
-    // instruction), then line by line through the wave's staging image into fragment order, in place: line j of every row holds the k-steps
+    // instruction), then line by line through the wave's staging image into fragment order: line j of every row holds the k-steps
     // 4 j .. 4 j + 3; chunk c of row t sits at t 128 + 16 (c ^ ((t >> 1) & 7)), conflict-free for both accesses
     auto load_rows = [&](auto &xreg, auto ks_c, const u16 *X, int n0, int stride) __attribute__((always_inline)) {
         constexpr int NK = decltype(ks_c)::value;
@@ -193,19 +193,13 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) xreg[4 * j + q] = as_bf16x8(*reinterpret_cast<const u32x4 *>(xr + (size_t)(8 * q) * stride + 64 * j));
     };
-    auto finish_rows = [&](auto &xreg, auto ks_c) __attribute__((always_inline)) {
-        constexpr int NK = decltype(ks_c)::value;
+    auto finish_line = [&](bf16x8 (&x4)[4]) __attribute__((always_inline)) {  // one line (4 row-wise registers) -> its 4 fragments, in place
         const int l = fresh_lane(), chunk = l & 7, rowi = l >> 3, r = l & 31, hf = l >> 5;
         const unsigned xw = st0 + rowi * 128, xr0 = st0 + r * 128;
 #pragma unroll
-        for (int j = 0; j < NK / 4; ++j) {
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<LDS_PTR(u32x4)>(xw + 1024 * q + (((chunk ^ ((rowi >> 1) + 4 * q)) & 7) << 4)) = as_u32x4(x4[q]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<LDS_PTR(u32x4)>(xw + 1024 * q + (((chunk ^ ((rowi >> 1) + 4 * q)) & 7) << 4)) = as_u32x4(xreg[4 * j + q]);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-                xreg[4 * j + m] = as_bf16x8(*reinterpret_cast<const LDS_PTR(u32x4)>(xr0 + ((((2 * m + hf) ^ (r >> 1)) & 7) << 4)));
-        }
+        for (int m = 0; m < 4; ++m) x4[m] = as_bf16x8(*reinterpret_cast<const LDS_PTR(u32x4)>(xr0 + ((((2 * m + hf) ^ (r >> 1)) & 7) << 4)));
     };
     constexpr int NPF = NT < 4 ? NT : 4;  // feature tiles of h in flight per wave
     auto load_h = [&](f32x4_t (&v)[4], unsigned hoff, int ft) __attribute__((always_inline)) {  // rows (lane >> 3) + 8 i, 128 bytes of feature tile ft
@@ -213,17 +207,11 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
         for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4_t *>(reinterpret_cast<const char *>(g.h) + (size_t)(hoff + (unsigned)(8 * i * 4 * D + 128 * ft)));
     };
 
-    // One round of a wave.  LAG = 0: the leading half, barrier in front of every even chunk of the stream; LAG = 1: the trailing half, barrier
-    // in front of every odd chunk.  (The stream of a tile has CO + 2 MB chunks, CO even: chunk parity is static below.)
-    auto round = [&](auto lag_c, int wt) __attribute__((always_inline)) {
-        constexpr int LAG = decltype(lag_c)::value;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int wt = w0 + rd * NW + wave;
         if (wt >= w1) {  // (uniform) no tile for this wave in the last round: pass the round's barriers, keep requesting
-            for (int c = 0; c < NPAIR; ++c) {
-                pair_head(E0);
-                next_slot();
-                next_slot();
-            }
-            return;
+            for (int c = 0; c < NPAIR; ++c) pair_head(E0);
+            continue;
         }
         const int n_wave = wt * 32;
         f32x16 out[NT];
@@ -236,10 +224,11 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
         {
             bf16x8 zreg[KZ];
             load_rows(zreg, std::integral_constant<int, KZ>(), g.Z, n_wave, g.zw);
-            finish_rows(zreg, std::integral_constant<int, KZ>());
+#pragma unroll
+            for (int j = 0; j < KZ / 4; ++j) finish_line(*reinterpret_cast<bf16x8(*)[4]>(&zreg[4 * j]));
 #pragma unroll
             for (int c = 0; c < CO; ++c) {
-                if ((c & 1) == LAG) pair_head(E0);
+                if ((c & 1) == 0) pair_head(E0);
                 const char *sb = smem + slot_c * CH + fresh_lane() * 16;
                 bf16x8 fr[PD];
 #pragma unroll
@@ -254,66 +243,120 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
             }
         }
 
-        // ---- mlp, block by block: up-projection -> GELU in registers -> down-projection ----
-        bf16x8 areg[KS];
-        load_rows(areg, std::integral_constant<int, KS>(), g.A, n_wave, D);
-        finish_rows(areg, std::integral_constant<int, KS>());
-        f32x4_t hv[NPF][4];
-        auto block = [&](int j, auto last_c) __attribute__((always_inline)) {
-            constexpr bool LAST = decltype(last_c)::value != 0;
-            // U(j): the chain of block j from its bias
-            if (LAG == 0) pair_head(E0);
-            f32x16 up;
+        // ---- activations: k-steps 0 .. KR - 1 as B fragments in registers, KR .. KS - 1 as lane-linear 1 KiB fragments in the wave's LDS image.
+        // The staging image IS the first 4 KiB of that image: the register lines go first, then the upper LDS line(s), the line that lands on
+        // the staging image itself last (its fragments are in registers when they overwrite it).
+        bf16x8 areg[KR];
+        {
+            bf16x8 raw[KS];
+            load_rows(raw, std::integral_constant<int, KS>(), g.A, n_wave, D);
+#pragma unroll
+            for (int j = 0; j < KR / 4; ++j) {
+                finish_line(*reinterpret_cast<bf16x8(*)[4]>(&raw[4 * j]));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) areg[4 * j + m] = raw[4 * j + m];
+            }
+            const unsigned fw = st0 + (unsigned)fresh_lane() * 16u;
+#pragma unroll
+            for (int j = KS / 4 - 1; j >= KR / 4; --j) {
+                finish_line(*reinterpret_cast<bf16x8(*)[4]>(&raw[4 * j]));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) *reinterpret_cast<LDS_PTR(u32x4)>(fw + 1024 * (4 * j + m - KR)) = as_u32x4(raw[4 * j + m]);
+            }
+        }
+
+        // ---- mlp, software-pipelined inside the wave: block j accumulates in up0 (even j) / up1 (odd j); its GELU runs in the MFMA shadows of
+        // D(j - 1) and U(j + 1) - a wave's vector instructions overlap only with its OWN MFMAs (its SIMD partner's do not: profiles/
+        // r06_experiments.txt section 5) - one pair of values behind every STRIDE-th MFMA, into gwE (even j) / gwO (odd j).
+        f32x16 up0, up1;
+        u32x4 gwE[2], gwO[2];
+        auto gelu_behind = [&](int i, int stride, int first_word, const f32x16 &ue, u32x4 (&gd)[2]) __attribute__((always_inline)) {
+            if (i % stride == stride - 1) {
+                const int s = first_word + i / stride;  // packed word s = accumulator registers 2 s, 2 s + 1
+                gd[s >> 2][s & 3] = gelu_pair_bf16(ue[2 * s], ue[2 * s + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // U(j): the chain of block j from its bias into `uc`; behind it the GELU words [first_word, first_word + CHF / stride) of `ue` -> gd
+        auto step_up = [&](f32x16 &uc, int j, int stride, int first_word, const f32x16 &ue, u32x4 (&gd)[2], auto gelu_c) __attribute__((always_inline)) {
+            constexpr bool DO_GELU = decltype(gelu_c)::value != 0;
             {
                 unsigned ba = b1_base + 16u * (unsigned)(fresh_lane() >> 5) + 128u * (unsigned)j;
                 asm volatile("" : "+v"(ba));  // (one per-lane base + immediates; no strength-reduced running pointer)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const f32x4_t b = *reinterpret_cast<const LDS_PTR(f32x4_t)>(ba + 32 * q4);
-                    up[4 * q4] = b[0]; up[4 * q4 + 1] = b[1]; up[4 * q4 + 2] = b[2]; up[4 * q4 + 3] = b[3];
+                    uc[4 * q4] = b[0]; uc[4 * q4 + 1] = b[1]; uc[4 * q4 + 2] = b[2]; uc[4 * q4 + 3] = b[3];
                 }
-                const char *sb = smem + slot_c * CH + fresh_lane() * 16;
-                bf16x8 fr[PD];
-#pragma unroll
-                for (int f = 0; f < PD; ++f) fr[f] = frag(sb, f);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    up = mfma32(fr[ks % PD], areg[ks], up);
-                    if (ks + PD < KS) fr[ks % PD] = frag(sb, ks + PD);
-                }
-                next_slot();
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // GELU(j): 16 values per lane, rounded to bf16 = the two B fragments of D(j) (accumulator registers 8 s .. 8 s + 7 are k-step s)
-            u32x4 gw[2];
+            const int l16 = fresh_lane() * 16;
+            const char *sb = smem + slot_c * CH + l16;
+            const char *ab = aimg + l16;
+            bf16x8 fr[PD], bfr[PD];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) gw[s >> 2][s & 3] = gelu_pair_bf16(up[2 * s], up[2 * s + 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            // D(j).  In front of the tile's last one: the h rows of the first NPF feature tiles are requested, behind the registers of the
-            // activations (dead now), so that they arrive under the chain.  Rows beyond N are read (h is padded to whole 256-row tiles), never written.
-            if (LAST) {
-                const int l = fresh_lane();
-                const unsigned hoff0 = (unsigned)(n_wave + (l >> 3)) * (unsigned)(4 * D) + 16u * (l & 7);
+            for (int f = 0; f < PD; ++f) fr[f] = frag(sb, f);
 #pragma unroll
-                for (int k = 0; k < NPF; ++k) load_h(hv[k], hoff0, k);
-                if (LAG == 1) pair_head(std::integral_constant<int, 4 * NPF>());
-            } else if (LAG == 1) pair_head(E0);
-            {
-                const char *sb = smem + slot_c * CH + fresh_lane() * 16;
-                bf16x8 fr[PD];
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + PD == KR || (ks == 0 && KR < PD)) {  // the first LDS-resident activation fragments: requested PD MFMAs ahead
 #pragma unroll
-                for (int f = 0; f < PD; ++f) fr[f] = frag(sb, f);
-#pragma unroll
-                for (int f = 0; f < CHF; ++f) {
-                    out[f >> 1] = mfma32(fr[f % PD], as_bf16x8(gw[f & 1]), out[f >> 1]);
-                    if (f + PD < CHF) fr[f % PD] = frag(sb, f + PD);
+                    for (int f = 0; f < PD; ++f) bfr[f] = frag(ab, f);
                 }
-                next_slot();
+                if (ks < KR) uc = mfma32(fr[ks % PD], areg[ks], uc);
+                else {
+                    uc = mfma32(fr[ks % PD], bfr[(ks - KR) % PD], uc);
+                    if (ks + PD < KS) bfr[(ks - KR) % PD] = frag(ab, ks - KR + PD);
+                }
+                if (ks + PD < KS) fr[ks % PD] = frag(sb, ks + PD);
+                if (DO_GELU) gelu_behind(ks, stride, first_word, ue, gd);
             }
+            next_slot();
             __builtin_amdgcn_sched_barrier(0);
         };
-        for (int j = 0; j + 1 < MB; ++j) block(j, std::integral_constant<int, 0>());
-        block(MB - 1, std::integral_constant<int, 1>());
+        // D(j): out^T += W2m(block j) gelu(u_j)^T with the packed words of `gw` as B fragments; behind it GELU words of `ue` -> gd
+        auto step_down = [&](const u32x4 (&gw)[2], int stride, int first_word, const f32x16 &ue, u32x4 (&gd)[2], auto gelu_c) __attribute__((always_inline)) {
+            constexpr bool DO_GELU = decltype(gelu_c)::value != 0;
+            const char *sb = smem + slot_c * CH + fresh_lane() * 16;
+            bf16x8 fr[PD];
+#pragma unroll
+            for (int f = 0; f < PD; ++f) fr[f] = frag(sb, f);
+#pragma unroll
+            for (int f = 0; f < CHF; ++f) {
+                out[f >> 1] = mfma32(fr[f % PD], as_bf16x8(gw[f & 1]), out[f >> 1]);
+                if (f + PD < CHF) fr[f % PD] = frag(sb, f + PD);
+                if (DO_GELU) gelu_behind(f, stride, first_word, ue, gd);
+            }
+            next_slot();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        std::integral_constant<int, 0> I0;
+        std::integral_constant<int, 1> I1;
+        constexpr int S8 = CHF / 8 > 0 ? CHF / 8 : 1, S4 = CHF / 4;  // one pair behind every S8-th MFMA: 8 words per chunk; every S4-th: 4 words
+        // pair (U0, U1): GELU(0) whole behind U(1)
+        pair_head(E0);
+        step_up(up0, 0, 1, 0, up1, gwE, I0);
+        step_up(up1, 1, S8, 0, up0, gwE, I1);
+        // pairs (D(j - 1), U(j + 1)), j = 1 .. MB - 2: GELU(j) behind both, half each
+        for (int j = 1; j + 1 <= MB - 2; j += 2) {  // (MB is even: host-checked - no parity branches, whose merged register state hipcc spills)
+            pair_head(E0);
+            step_down(gwE, S4, 0, up1, gwO, I1);         // D(j - 1) | GELU(j) words 0-3      (j odd)
+            step_up(up0, j + 1, S4, 4, up1, gwO, I1);    // U(j + 1) | GELU(j) words 4-7
+            pair_head(E0);
+            step_down(gwO, S4, 0, up0, gwE, I1);         // D(j)     | GELU(j + 1) words 0-3
+            step_up(up1, j + 2, S4, 4, up0, gwE, I1);    // U(j + 2) | GELU(j + 1) words 4-7
+        }
+        // pair (D(MB - 2), D(MB - 1)): GELU(MB - 1) (odd block: up1) whole behind D(MB - 2).  Between the two the h rows of the first NPF feature
+        // tiles are requested, behind the registers of the accumulator tiles and one fragment pair (dead now), so that they arrive under the last
+        // chain.  Rows beyond N are read (h is padded to whole 256-row tiles), never written.
+        f32x4_t hv[NPF][4];
+        pair_head(E0);
+        step_down(gwE, S8, 0, up1, gwO, I1);
+        {
+            const int l = fresh_lane();
+            const unsigned hoff0 = (unsigned)(n_wave + (l >> 3)) * (unsigned)(4 * D) + 16u * (l & 7);
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) load_h(hv[k], hoff0, k);
+        }
+        step_down(gwO, 1, 0, up1, gwE, I0);
 
         // ---- epilogue: h += gate (out + b2); LayerNorm + modulate of the next sub-block ----
         const int le = fresh_lane(), chunk = le & 7, rowi = le >> 3, r = le & 31, hf = le >> 5;
@@ -387,17 +430,6 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
                 }
             }
         }
-    };
-
-    if (wave < 4) {  // (uniform)
-        for (int rd = 0; rd < rounds; ++rd) round(std::integral_constant<int, 0>(), w0 + rd * NW + wave);
-        // ... the leading half passes one more barrier at the end: the same number for every wave
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-    } else {
-        // the trailing half starts one chunk late: its first barrier is the workgroup's barrier 0, behind which it computes chunk 0 only
-        pair_head(E0);
-        for (int rd = 0; rd < rounds; ++rd) round(std::integral_constant<int, 1>(), w0 + rd * NW + wave);
     }
     wait_vmcnt<0>();  // the ring's run-ahead requests must not land in LDS after the workgroup has gone
 }

@@ -177,7 +177,7 @@ int lsl_model_set_attention_mode(lsl_model *m, int32_t mode) try {
 int lsl_model_set_tail(lsl_model *m, int32_t on) try {
     if (!m || (on != 0 && on != 1)) return fail(-1, "tail must be 0 or 1");
     if (on && !tail_shape_ok(m->d.hidden, m->HHD, m->d.mlp_dim))
-        return fail(-21, "no tail kernel for this model (hidden 256 with heads * head_dim_pad = 256, mlp_dim a multiple of 32; LSL_TAIL=0 disables it)");
+        return fail(-21, "no tail kernel for this model (hidden 256 with heads * head_dim_pad = 256, mlp_dim a multiple of 64; LSL_TAIL=0 disables it)");
     if (m->tail != (on == 1)) drop_graphs(m);
     m->tail = on == 1;
     return 0;
