@@ -151,11 +151,11 @@ int lsl_model_set_attention_mode(lsl_model *m, int32_t mode);
 
 /* Decomposition of a ParallelMLPAttentionV2 sub-block (mmdit.py:240-249) behind the attention.  0 (default): linear1 computes q | k | v | mlp,
  * linear2 and the next LayerNorm are kernels of their own.  1: linear1 computes q | k | v only and ONE row-owning kernel (k_tail) runs the mlp
- * up-projection, GELU, linear2 over [attention | gelu(mlp)], the gated residual update and the next sub-block's LayerNorm + modulate: 7.5
- * instead of 12.3 KB of HBM traffic per token and sub-block at hidden 256 / mlp 1024, faster from about 10^5 tokens per pass, slower below
+ * up-projection, GELU, linear2 over [attention | gelu(mlp)], the gated residual update and the next sub-block's LayerNorm + modulate: 8.6
+ * instead of 13.2 KB of measured HBM traffic per token and sub-block at hidden 256 / mlp 1024, faster from about 10^5 tokens per pass, slower below
  * (a workgroup streams the whole weight image per 256 tokens).  The two forms are not bit-identical (other summation order in linear2 and in
  * the row statistics; same error against the fp32 reference), so the choice belongs to the MODEL HANDLE - never to the batch: a trajectory's
- * bits stay the same in any batch, shard or pass.  Returns -21 if the model has no instance (hidden 256 with heads * head_dim_pad = 256).
+ * bits stay the same in any batch, shard or pass.  Returns -21 if the model has no instance (hidden 256 with heads * head_dim_pad = 256 and mlp_dim a multiple of 64).
  * Environment LSL_TAIL=1 / 0 sets the default of new handles / disables the form (A/B runs, tests). */
 int lsl_model_set_tail(lsl_model *m, int32_t on);
 int32_t lsl_model_tail(const lsl_model *m); /* 1 if the handle runs the tail form */
