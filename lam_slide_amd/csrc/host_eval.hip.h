@@ -123,7 +123,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
                           ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, F1, n, m->HHD, d.mlp_dim,
                           pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, 0, planes ? 1 : 0, npad};
         launch_linear1_ts(d.head_dim_pad, D, la, st);
-        m->prof.label(0, "k_linear1_ts<%d, %d>%s", d.head_dim_pad, D, tail ? " (q | k | v)" : "");
+        m->prof.label(0, "k_linear1_ts<%d, %d, %d>%s", d.head_dim_pad, D, linear1_ts_waves(D, n), tail ? " (q | k | v)" : "");
     } else if (d.head_dim_pad == 32) {
         EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                          ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->HHD, d.mlp_dim,

@@ -177,11 +177,12 @@ bool gemm_rows_walk(int F, int N) {
 
 // linear1 on the token-stationary kernel (k_lin1.hip.h): hidden sizes 128 / 256 / 384 / 512, sections (q | k | v | mlp) on multiples of 64
 // features.  Same bits as the tile kernels below (tools/lin1_harness.hip), so the choice between them may depend on the launch size.
-template <int HDP, int K>
+template <int HDP, int K, int NW = 8>
 void launch_linear1_ts_t(const Lin1Args &a, hipStream_t st) {
-    auto kern = k_linear1_ts<HDP, K>;
+    using C = Lin1Cfg<HDP, K, NW>;
+    auto kern = k_linear1_ts<HDP, K, NW>;
     LSL_ALLOW_LDS(kern, (size_t)163840);
-    const int ntile = (a.N + 255) / 256, nb = a.F / 32;
+    const int ntile = (a.N + C::TT - 1) / C::TT, nb = a.F / 32;
     const long units = (long)ntile * nb;
     int grid = (int)std::min<long>(device_cus(), units / 2);
     Lin1Args b = a;
@@ -190,8 +191,20 @@ void launch_linear1_ts_t(const Lin1Args &a, hipStream_t st) {
     const int wpt = std::min(device_cus() / ntile, nb / 2);
     b.wpt = align && wpt >= 2 ? wpt : 0;
     if (b.wpt) grid = b.wpt * ntile;
-    const size_t lds = Lin1Cfg<HDP, K>::lds_bytes(a.F);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, b);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), C::lds_bytes(a.F), st, b);
+}
+// K = 512, few tokens (md17_bench B = 1: 7 680): 4-wave workgroups on 128-token tiles - twice the tiles, half the activation prologue per
+// workgroup, one wave per SIMD (512 registers: no scratch).  Same bits (tools/lin1_harness.hip -DLIN1_NW=4); 3 840 tokens 24.0 -> 19.9 us,
+// 7 680 34.4 -> 30.4, 15 360 50.4 -> 53.0 (so: up to 10 240); slower at every size for K <= 384 and at every large launch
+// (profiles/r06_experiments.txt section 6).
+int linear1_ts_waves(int D, int N) {
+    static const int nw4_max = tune_int("LSL_LIN1_NW4_MAX", 10240);
+    return D == 512 && N <= nw4_max ? 4 : 8;
+}
+template <int HDP>
+void launch_linear1_ts_512(const Lin1Args &a, hipStream_t st) {
+    if (linear1_ts_waves(512, a.N) == 4) return launch_linear1_ts_t<HDP, 512, 4>(a, st);
+    return launch_linear1_ts_t<HDP, 512, 8>(a, st);
 }
 bool linear1_ts_ok(int hdp, int D, int F1, int HHD, int N) {
     static const int on = tune_int("LSL_LIN1_TS", 1);
@@ -203,11 +216,11 @@ void launch_linear1_ts(int hdp, int D, const Lin1Args &a, hipStream_t st) {
         case 0: return launch_linear1_ts_t<32, 128>(a, st);
         case 1: return launch_linear1_ts_t<32, 256>(a, st);
         case 2: return launch_linear1_ts_t<32, 384>(a, st);
-        case 3: return launch_linear1_ts_t<32, 512>(a, st);
+        case 3: return launch_linear1_ts_512<32>(a, st);
         case 4: return launch_linear1_ts_t<16, 128>(a, st);
         case 5: return launch_linear1_ts_t<16, 256>(a, st);
         case 6: return launch_linear1_ts_t<16, 384>(a, st);
-        default: return launch_linear1_ts_t<16, 512>(a, st);
+        default: return launch_linear1_ts_512<16>(a, st);
     }
 }
 

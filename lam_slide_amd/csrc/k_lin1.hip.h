@@ -56,7 +56,7 @@ struct Lin1Args {
 #define LIN1_B2 1
 #endif
 
-template <int HDP, int K>
+template <int HDP, int K, int NW = 8>
 struct Lin1Cfg {
     static_assert(K % 128 == 0 && K <= 512, "hidden sizes 128 / 256 / 384 / 512");
     static constexpr int KS = K / 16;                   // k-steps = B fragments a wave keeps
@@ -69,9 +69,11 @@ struct Lin1Cfg {
     static constexpr int BLK = 32 * PITCH;              // one weight block
     static constexpr int NS = (LIN1_B2 && K <= 256) ? 4 : 3;  // ring slots
     static constexpr int RING = NS * BLK;
-    static constexpr int STAGE = 8 * 4096;              // wave-private output staging
+    static_assert(NW == 8 || NW == 4, "two waves per SIMD (256-token tiles) or one (128-token tiles)");
+    static constexpr int TT = 32 * NW;                  // tokens per tile
+    static constexpr int STAGE = NW * 4096;             // wave-private output staging
     static constexpr int LPR = ROWB / 16;               // active lanes of a DMA instruction: 64 / 48 / 32 / 16
-    static constexpr int PPW = 4;                       // DMA instructions (rows) per wave per block
+    static constexpr int PPW = 32 / NW;                 // DMA instructions (rows) per wave per block
     static constexpr size_t lds_bytes(int F) { return (size_t)RING + STAGE + (size_t)F * 4; }
 };
 
@@ -97,9 +99,9 @@ __device__ __forceinline__ float lin1_gelu(float x) {
     return fmaf(-ax, h, relu);
 }
 
-template <int HDP, int K>
-__global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
-    using C = Lin1Cfg<HDP, K>;
+template <int HDP, int K, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_linear1_ts(Lin1Args g) {
+    using C = Lin1Cfg<HDP, K, NW>;
     constexpr int KS = C::KS, BLK = C::BLK, PPW = C::PPW, ROWB = C::ROWB;
     constexpr int NCO = HDP == 32 ? 8 : 4;  // rotation pairs a lane owns per head
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     float *const bias_lds = reinterpret_cast<float *>(smem + C::RING + C::STAGE);
 
     const int NB = g.F >> 5;  // weight blocks (F is a multiple of 64: sections start on multiples of 64)
-    const int ntile = (g.N + 255) >> 8;
+    const int ntile = (g.N + C::TT - 1) / C::TT;
     const long U = (long)ntile * NB;
     // Work split.  Large launches: the (tile, block) sequence cut evenly (on even blocks: sections start on multiples of 64 features and
     // blocks alternate accumulators) over the persistent workgroups; a range that crosses a tile boundary pays a second segment
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     // form of this kernel (one wave per SIMD, 64 tokens and the whole 512-register file per wave, each weight fragment read once for two
     // MFMAs) was built and is bit-identical, but as scheduled by hipcc it is 11 % slower at K = 256 and spills at K = 512
     // (profiles/r03_experiments.txt).
-    for (int i = tid * 4; i < g.F; i += 512 * 4) *reinterpret_cast<float4 *>(bias_lds + i) = *reinterpret_cast<const float4 *>(g.bias + i);
+    for (int i = tid * 4; i < g.F; i += NW * 64 * 4) *reinterpret_cast<float4 *>(bias_lds + i) = *reinterpret_cast<const float4 *>(g.bias + i);
 
     // ---- weight ring: block -> slot; wave w requests rows 4 w .. 4 w + 3 of a block, one LDS-DMA instruction per row ----
     // The DMA instruction is inline asm ON PURPOSE: behind the builtin, hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of the next LDS
@@ -145,21 +147,25 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     // writes SCC, which the statement declares (hipcc keeps ring-slot compares live in SCC across it otherwise: wrong slots, now and then).
     const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))(smem);
     const unsigned lane_src = lane * 16;  // byte offset of the lane's 16-byte chunk in a weight row
-    const char *const w_rows = reinterpret_cast<const char *>(g.W) + (size_t)(4 * wave) * ROWB;  // row 4 w of block 0
+    const char *const w_rows = reinterpret_cast<const char *>(g.W) + (size_t)(PPW * wave) * ROWB;  // row PPW w of block 0
     auto issue_piece = [&](const char *src, unsigned dst, auto ic) __attribute__((always_inline)) {
-        constexpr int I = decltype(ic)::value;
+        constexpr int I = decltype(ic)::value & 3;
+        if (decltype(ic)::value >= 4) {  // (4-wave form: rows 4 .. 7 of the wave's share; the immediate offset reaches 3 rows at K = 512)
+            src += 4 * ROWB;
+            dst += 4 * C::PITCH;
+        }
         const unsigned ls = lane_src;  // (an odr-use: a generic lambda does not capture a variable that only appears as an asm operand)
         if (C::LPR == 64 || lane < C::LPR) {
             // (s_nop 4 on the first piece: src / dst may come straight from a scalar ALU instruction and nothing pads the 5 wait states of
             // "SALU writes SGPR -> VMEM reads it" inside asm; the later pieces read the same registers, long since written)
-            if (I == 0)
+            if (I == 0 || decltype(ic)::value >= 4)
                 asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4" ::"v"(ls), "s"(src), "s"(dst), "n"(16 * I), "n"(ROWB * I) : "memory", "scc");
             else
                 asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4" ::"v"(ls), "s"(src), "s"(dst), "n"(16 * I), "n"(ROWB * I) : "memory", "scc");
         }
     };
     auto req_src = [&](int blk) __attribute__((always_inline)) { return w_rows + (size_t)blk * (32 * ROWB); };
-    auto req_dst = [&](int slot) __attribute__((always_inline)) { return lds0 + slot * BLK + 4 * wave * C::PITCH; };
+    auto req_dst = [&](int slot) __attribute__((always_inline)) { return lds0 + slot * BLK + PPW * wave * C::PITCH; };
     auto issue = [&](int blk, int slot) __attribute__((always_inline)) {
         const char *src = req_src(blk);
         const unsigned dst = req_dst(slot);
@@ -167,6 +173,12 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         issue_piece(src, dst, std::integral_constant<int, 1>());
         issue_piece(src, dst, std::integral_constant<int, 2>());
         issue_piece(src, dst, std::integral_constant<int, 3>());
+        if (PPW == 8) {
+            issue_piece(src, dst, std::integral_constant<int, 4>());
+            issue_piece(src, dst, std::integral_constant<int, 5>());
+            issue_piece(src, dst, std::integral_constant<int, 6>());
+            issue_piece(src, dst, std::integral_constant<int, 7>());
+        }
     };
     const int aoff = r * C::PITCH + 16 * hf;  // A fragment of k-step ks: + 32 ks
 
@@ -390,11 +402,21 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
                 }
                 if (SL == 1) flush_store(1, pk);
             }
+            constexpr int PS = PPW / 4;  // pieces per slice: 1 (8 waves), 2 (4 waves)
             if (!B2) {
-                if (SL >= 2 && SL < 2 + PPW) issue_piece(src, dst, std::integral_constant<int, (SL >= 2 && SL < 2 + PPW) ? SL - 2 : 0>());
-            } else if (PAR == 1) {  // both blocks of the next pair: 8 pieces behind the 8 slices (PAR == 1 steps never flush)
-                if (SL >= 0 && SL < PPW) issue_piece(src, dst, std::integral_constant<int, (SL >= 0 && SL < PPW) ? SL : 0>());
-                if (SL >= PPW && SL < 2 * PPW) issue_piece(src2, dst2, std::integral_constant<int, (SL >= PPW && SL < 2 * PPW) ? SL - PPW : 0>());
+                if (SL >= 2 && SL < 6) {
+                    issue_piece(src, dst, std::integral_constant<int, (SL >= 2 && SL < 6) ? PS * (SL - 2) : 0>());
+                    if (PS == 2) issue_piece(src, dst, std::integral_constant<int, (SL >= 2 && SL < 6) ? PS * (SL - 2) + 1 : 0>());
+                }
+            } else if (PAR == 1) {  // both blocks of the next pair: their pieces behind the 8 slices (PAR == 1 steps never flush)
+                if (SL >= 0 && SL < 4) {
+                    issue_piece(src, dst, std::integral_constant<int, (SL >= 0 && SL < 4) ? PS * SL : 0>());
+                    if (PS == 2) issue_piece(src, dst, std::integral_constant<int, (SL >= 0 && SL < 4) ? PS * SL + 1 : 0>());
+                }
+                if (SL >= 4 && SL < 8) {
+                    issue_piece(src2, dst2, std::integral_constant<int, (SL >= 4 && SL < 8) ? PS * (SL - 4) : 0>());
+                    if (PS == 2) issue_piece(src2, dst2, std::integral_constant<int, (SL >= 4 && SL < 8) ? PS * (SL - 4) + 1 : 0>());
+                }
             }
         });
         if (!B2) {
@@ -471,7 +493,7 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
     __syncthreads();  // bias vector in LDS
     while (left > 0) {  // one segment = blocks [b0, b1) of one token tile; b0, b1 even
         const int b1 = NB - b0 < left ? NB : b0 + left;
-        n_wave = tile * 256 + wave * 32;
+        n_wave = tile * C::TT + wave * 32;
         row_q = reinterpret_cast<const char *>(g.qkv) + (size_t)n_wave * stride_q;
         row_z = reinterpret_cast<const char *>(g.z) + (size_t)n_wave * stride_z - 4 * (size_t)g.HHD;  // (z column of feature f: f - 2 HHD)
         // the wave's tokens: B fragments of all k-steps (X is padded to whole tiles)
@@ -542,7 +564,7 @@ __global__ void __launch_bounds__(512, 2) k_linear1_ts(Lin1Args g) {
         co_ready = false;
         if (left_next > 0) {  // (uniform) the next segment: tile + 1 from block 0, i.e. the q section
             asm volatile("" ::: "memory");
-            const int nw = (tile + 1) * 256 + wave * 32;
+            const int nw = (tile + 1) * C::TT + wave * 32;
             load_x(nw);
             if (b1 - 1 >= 2 * qb) {  // the drain below is not a q / k block: co is free for the next segment's q table
                 const unsigned nn2 = (unsigned)min(nw + r, g.N - 1);

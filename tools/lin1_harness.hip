@@ -17,6 +17,10 @@
 #include "../lam_slide_amd/csrc/k_lin1.hip.h"
 #endif
 
+#ifndef LIN1_NW
+#define LIN1_NW 8  // waves per workgroup of the token-stationary kernel (4: 128-token tiles, one wave per SIMD)
+#endif
+
 #define CK(x)                                                                  \
     do {                                                                       \
         hipError_t e_ = (x);                                                   \
@@ -89,14 +93,15 @@ void run_case(int N, int D, int H, int mlp_ratio, int iters, int grid_new, int p
 #else
     Lin1Args la{W, X, b, rq, rk, qkv1, z1, F, N, HHD, M, pdiv, pmod, magic_of(pdiv), magic_of(pmod), inv_hd, premul, 1};
 #endif
-    auto knew = k_linear1_ts<HDP, K>;
-    const size_t lds_new = Lin1Cfg<HDP, K>::lds_bytes(F);
+    auto knew = k_linear1_ts<HDP, K, LIN1_NW>;
+    const size_t lds_new = Lin1Cfg<HDP, K, LIN1_NW>::lds_bytes(F);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(knew), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-    const long units = (long)((N + 255) / 256) * (F / 32);
+    constexpr int TT = 32 * LIN1_NW;
+    const long units = (long)((N + TT - 1) / TT) * (F / 32);
     int gnew = grid_new;
     if (gnew > units / 2) gnew = (int)(units / 2);
     if (getenv("LIN1_WPT")) {  // tile-aligned split for small launches, as launch_linear1_ts_t chooses it
-        const int ntile = (N + 255) / 256, wpt = std::min(256 / ntile, F / 64);
+        const int ntile = (N + TT - 1) / TT, wpt = std::min(256 / ntile, F / 64);
         if (wpt >= 2) { la.wpt = wpt; gnew = wpt * ntile; }
     }
     printf("  lds old %zu new %zu, grid old %d new %d (wpt %d)\n", lds_old, lds_new, grid_old, gnew, la.wpt);
@@ -104,7 +109,7 @@ void run_case(int N, int D, int H, int mlp_ratio, int iters, int grid_new, int p
     hipLaunchKernelGGL(kold, dim3(grid_old), dim3(512), lds_old, 0, ga, e);
     CK(hipDeviceSynchronize());
     printf("  old kernel ran\n"); fflush(stdout);
-    hipLaunchKernelGGL(knew, dim3(gnew), dim3(512), lds_new, 0, la);
+    hipLaunchKernelGGL(knew, dim3(gnew), dim3(64 * LIN1_NW), lds_new, 0, la);
     CK(hipDeviceSynchronize());
     printf("  new kernel ran\n"); fflush(stdout);
 
@@ -158,7 +163,7 @@ void run_case(int N, int D, int H, int mlp_ratio, int iters, int grid_new, int p
         for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(kold, dim3(grid_old), dim3(512), lds_old, 0, ga, e);
         CK(hipEventRecord(ev1, 0)); CK(hipEventSynchronize(ev1)); CK(hipEventElapsedTime(&ms_old, ev0, ev1));
         CK(hipEventRecord(ev0, 0));
-        for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(knew, dim3(gnew), dim3(512), lds_new, 0, la);
+        for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(knew, dim3(gnew), dim3(64 * LIN1_NW), lds_new, 0, la);
         CK(hipEventRecord(ev1, 0)); CK(hipEventSynchronize(ev1)); CK(hipEventElapsedTime(&ms_new, ev0, ev1));
         printf("  round %d: old %.4f ms/launch (%.0f TF/s)   new %.4f ms/launch (%.0f TF/s)\n", round, ms_old / iters,
                flop / (ms_old / iters * 1e-3) * 1e-12, ms_new / iters, flop / (ms_new / iters * 1e-3) * 1e-12);
