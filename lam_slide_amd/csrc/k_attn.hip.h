@@ -371,6 +371,9 @@ __global__ void __launch_bounds__(NW * 64, 4) k_attention_rows(AttnArgs a) {  //
 #ifndef LSL_ATTN_XL_UNROLL
 #define LSL_ATTN_XL_UNROLL 1
 #endif
+#ifndef LSL_ATTN_XL_PIPE
+#define LSL_ATTN_XL_PIPE 1  // chunked-key form, 32-wide heads: exponentials of tile kt behind the MFMAs of tiles kt / kt + 1 (below)
+#endif
 template <int HDP, bool LONG, bool XL = false, bool ONES = false, bool PACK = false>
 __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
     static_assert(LONG || !XL, "chunked keys / grouped queries exist for the LONG form only");
@@ -667,9 +670,77 @@ __global__ void __launch_bounds__(512, 4) k_attention_stream(AttnArgs a) {
                     else if (!XL) {
 #pragma unroll 2
                         for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, zero));  // (fully unrolled, hipcc hoists every fragment address and spills)
-                    } else {
+                    } else if (!LSL_ATTN_XL_PIPE || KS != 2 || !ONES) {  // (the form without the denominator column has two more MFMAs and 16 more live registers per tile: it spills at 128)
 #pragma unroll LSL_ATTN_XL_UNROLL
                         for (int kt = 0; kt < nkt; ++kt) tile(kt, scores(kt, zero));
+                    } else {
+                        // Chunked keys (T = 1000: 32 key tiles per query tile): the loop is compute-bound, and on this chip a wave's vector
+                        // instructions overlap only with its OWN MFMAs (profiles/r06_experiments.txt section 5) - so the exponentials of key tile
+                        // kt sit, a quarter at a time, behind the score MFMAs of tile kt + 1 and the P.V MFMAs of tile kt, each group fenced.
+                        // Same operations on every element in the same order as the plain loop: same bits.
+                        auto kfrag = [&](int kt, int c) __attribute__((always_inline)) {
+                            return as_bf16x8(*reinterpret_cast<const u32x4 *>(Ks + k_swz<HDP>(krow0 + kt * 32 + r, c + hf)));
+                        };
+                        auto vfrag = [&](int kt, int s2) __attribute__((always_inline)) {
+                            const char *vb = Vs + (krow0 + kt * 32 + 16 * s2) * ROWB + v_off;
+                            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb));
+                            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(vb + 8 * ROWB));
+                            typedef __attribute__((ext_vector_type(8))) short s16x8;
+                            const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            return __builtin_bit_cast(bf16x8, vv);
+                        };
+                        auto exp4 = [&](const f32x16 &t, int q, float (&p)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(t[4 * q + e]);
+                            asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));  // (computed HERE: hipcc otherwise sinks a quarter to its use, out of its MFMA shadow)
+                        };
+                        f32x16 t = scores(0, zero);
+                        bf16x8 k0 = kfrag(nkt > 1 ? 1 : 0, 0), k1 = kfrag(nkt > 1 ? 1 : 0, 2);
+                        // MFMA order per step: P.V second half of tile kt - 1 (carried: pwc, vbc; the first step's is 0 x 0 onto the accumulator: no
+                        // bit changes), the two score MFMAs of tile kt + 1, P.V first half of tile kt - a quarter of tile kt's exponentials and
+                        // two packs behind each: 40 vector cycles per 32-cycle MFMA, nothing of the loop outside an MFMA shadow
+                        u32x4 pwc = {0u, 0u, 0u, 0u};
+                        bf16x8 vbc = as_bf16x8(pwc);
+                        auto step = [&](const f32x16 &ti, f32x16 &tn, int kt) __attribute__((always_inline)) {
+                            const bf16x8 va = vfrag(kt, 0);
+                            float pa[4], pb[4];
+                            o = mfma32(vbc, as_bf16x8(pwc), o);
+                            exp4(ti, 0, pa);
+                            __builtin_amdgcn_sched_barrier(0);
+                            vbc = vfrag(kt, 1);
+                            tn = mfma32(k0, qf[0], zero);
+                            exp4(ti, 1, pb);
+                            const u32x4 pw0 = {pack2(pa[0], pa[1]), pack2(pa[2], pa[3]), pack2(pb[0], pb[1]), pack2(pb[2], pb[3])};
+                            __builtin_amdgcn_sched_barrier(0);
+                            tn = mfma32(k1, qf[1], tn);
+                            exp4(ti, 2, pa);
+                            const int kn = kt + 2 < nkt ? kt + 2 : kt + 1;  // (the fragments of the tile after the next: read one step ahead)
+                            k0 = kfrag(kn, 0);
+                            k1 = kfrag(kn, 2);
+                            __builtin_amdgcn_sched_barrier(0);
+                            o = mfma32(va, as_bf16x8(pw0), o);
+                            exp4(ti, 3, pb);
+                            pwc = u32x4{pack2(pa[0], pa[1]), pack2(pa[2], pa[3]), pack2(pb[0], pb[1]), pack2(pb[2], pb[3])};
+                            if (last_c && kt + 2 == nkt_last && ragged) {  // (uniform) the chunk's last tile holds clamped rows past the sequence
+#pragma unroll
+                                for (int e = 0; e < 16; ++e)
+                                    if (acc_row(e, hf) >= last_rows) tn[e] = -INFINITY;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        };
+                        f32x16 t2;  // (steps in pairs: the two score tiles swap roles, no copies)
+                        int kt = 0;
+#pragma unroll 1
+                        for (; kt + 2 < nkt; kt += 2) {
+                            step(t, t2, kt);
+                            step(t2, t, kt + 1);
+                        }
+                        if (kt + 1 < nkt) {  // (uniform)
+                            step(t, t2, kt);
+                            t = t2;
+                        }
+                        o = mfma32(vbc, as_bf16x8(pwc), o);
+                        tile(nkt - 1, t);
                     }
                 } else {
 #pragma unroll 1

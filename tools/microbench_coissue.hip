@@ -14,7 +14,7 @@
 #include "../lam_slide_amd/csrc/common.hip.h"
 
 #ifndef VKIND
-#define VKIND 0  // the vector work: 0 gelu_pair_bf16 (packed-fp32 polynomial), 1 two gelu_fast + pack (scalar FMAs), 2 13 plain v_fma_f32 per pair, 3 4 v_exp_f32 per pair
+#define VKIND 0  // the vector work: 0 gelu_pair_bf16 (packed-fp32 polynomial), 1 two gelu_fast + pack (scalar FMAs), 2 13 plain v_fma_f32 per pair, 3 4 v_exp_f32 per pair, 4 both (independent)
 #endif
 __device__ __forceinline__ unsigned vwork(float x0, float x1) {
     if (VKIND == 0) return gelu_pair_bf16(x0, x1);
@@ -24,6 +24,13 @@ __device__ __forceinline__ unsigned vwork(float x0, float x1) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { a = fmaf(a, 0.99f, b); b = fmaf(b, 1.01f, a); }
         return __float_as_uint(fmaf(a, b, 1.0f));
+    }
+    if (VKIND == 4) {  // kinds 2 and 3 together, independent of each other: do the transcendental and the plain vector instructions of ONE wave overlap?
+        float a = x0, b = x1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { a = fmaf(a, 0.99f, b); b = fmaf(b, 1.01f, a); }
+        return __float_as_uint(fmaf(a, b, 1.0f)) ^ __float_as_uint(__builtin_amdgcn_exp2f(x0) + __builtin_amdgcn_exp2f(x1)) ^
+               __float_as_uint(__builtin_amdgcn_exp2f(x0 * 0.5f) + __builtin_amdgcn_exp2f(x1 * 0.5f));
     }
     return __float_as_uint(__builtin_amdgcn_exp2f(x0) + __builtin_amdgcn_exp2f(x1)) ^ __float_as_uint(__builtin_amdgcn_exp2f(x0 * 0.5f) + __builtin_amdgcn_exp2f(x1 * 0.5f));
 }
