@@ -21,6 +21,9 @@
 //     whole 128-byte row segments;
 //   * work = (token tile, block) pairs in one linear order, cut into equal contiguous ranges: every workgroup does the same number of
 //     blocks whatever the tile count (no fractional last round).
+//   * NW = 4 (round 6): the same kernel on 4-wave workgroups and 128-token tiles - one wave per SIMD (512 registers: no scratch at K = 512), every
+//     wave requests 8 rows of a block.  Same bits.  Slower wherever the launch is large (a lone wave's latencies have no partner to fill them:
+//     709.8 vs 610.9 us at 245 760 x 512), faster where the activation prologue dominates: K = 512 up to ~10 000 tokens (host_launch.hip.h).
 //
 // Bits: every output element is bias + the k-ascending chain of 16-deep MFMA steps, then EpiLinear1's arithmetic in the same order:
 // identical to k_gemm_glds for any launch size (tools/lin1_harness.hip compares the two kernels bit for bit).

@@ -397,6 +397,30 @@ def test_batch_independence_across_the_linear2_tiling_threshold_384(dev):
     assert torch.isfinite(full).all()
 
 
+def test_batch_independence_across_the_linear1_wave_count_threshold_512(dev):
+    """512-wide models: linear1 runs 4-wave workgroups on 128-token tiles up to 10 240 tokens per pass and 8-wave workgroups on 256-token
+    tiles above (host_launch.hip.h, launch_linear1_ts_512; tools/lin1_harness.hip -DLIN1_NW=4 compares both with the tile kernel bit for
+    bit).  Here through the sampler: trajectory k of a 3-trajectory call (23 040 tokens: 8 waves) against the same trajectory sampled alone
+    (7 680 tokens - md17_bench B = 1 -: 4 waves), and a ragged length whose last 128-token tile is partial."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler
+    from oracle import latent_net
+    sh = latent_net.NetShape(depth=2, in_dim=32, hidden_size=512, num_heads=16, mlp_ratio=2)
+    net = build_net(sh, latent_net.random_params(sh, seed=17), dev)
+    for T, L in ((30, 256), (7, 251)):
+        g = torch.Generator().manual_seed(5)
+        lat = torch.randn(3, T, L, 32, generator=g).to(dev)
+        init = torch.randn(3, T, L, 32, generator=g).to(dev)
+        drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(0, 2), sampling_kwargs={"sampling_method": "euler", "num_steps": 3})
+        full = drv.sample_latents(lat, init=init)
+        if T * L * 3 > 10240:
+            for k in (0, 2):
+                assert torch.equal(full[k:k + 1], drv.sample_latents(lat[k:k + 1], init=init[k:k + 1])), f"trajectory {k}: alone vs in the batch of 3"
+        else:  # (both sides on the 4-wave form; the 8-wave side through a batch large enough to cross the threshold)
+            big = torch.cat([lat, lat]), torch.cat([init, init])
+            assert torch.equal(full, drv.sample_latents(big[0], init=big[1])[:3]), "ragged length: 3 trajectories alone vs inside 6"
+        assert torch.isfinite(full).all()
+
+
 def test_pass_size_rule_equal_passes_under_the_token_cap(dev):
     """lsl_pass_size: a pass holds at most 256 Ki tokens, and a batch that needs several passes is cut into EQUAL ones (1024 trajectories of
     640 tokens: 342 + 342 + 340, not 409 + 409 + 206 - the short pass fills the chip worse); results do not depend on it (test above)."""
