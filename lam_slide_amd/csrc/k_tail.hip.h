@@ -151,26 +151,44 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
         asm volatile("s_add_u32 m0, %2, 0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(ls), "s"(src), "s"(dst), "n"(1024 * I) : "memory", "scc");
     };
     int p_src = 0, slot_d = 0;  // next PAIR of the stream to request (index in [0, NPAIR)), and its first slot (0 or 2)
-    auto issue_pair = [&]() __attribute__((always_inline)) {
-        const char *src = w_base + (size_t)p_src * (2 * CH);
-        const unsigned dst = lds0 + slot_d * CH + wave * PPW * 1024;
-        issue_piece(src, dst, std::integral_constant<int, 0>());
-        if constexpr (PPW > 1) issue_piece(src, dst, std::integral_constant<int, 1>());
-        issue_piece(src + CH, dst + CH, std::integral_constant<int, 0>());
-        if constexpr (PPW > 1) issue_piece(src + CH, dst + CH, std::integral_constant<int, 1>());
+    const char *d_src = nullptr;  // the pair being requested: its 2 PPW pieces are issued one at a time INSIDE the MFMA chain of the pair's
+    unsigned d_dst = 0;           // first chunk (an LDS-DMA instruction costs the wave ~ 100 cycles of issue: k_lin1.hip.h "side jobs")
+    auto pair_begin = [&]() __attribute__((always_inline)) {
+        d_src = w_base + (size_t)p_src * (2 * CH);
+        d_dst = lds0 + slot_d * CH + wave * PPW * 1024;
         p_src = p_src + 1 == NPAIR ? 0 : p_src + 1;
         slot_d ^= 2;
     };
-    static_assert(PPW <= 2, "D <= 256");
+    static_assert(PPW >= 1 && PPW <= 2 && CHF >= 8, "2 PPW pieces per wave and pair, behind MFMAs 1, 3, 5, 7 of a chunk");
+    auto issue_q = [&](auto qc) __attribute__((always_inline)) {  // piece q of the pair: chunk q / PPW, fragment q % PPW of the wave's PPW
+        constexpr int Q = decltype(qc)::value;
+        if constexpr (Q < 2 * PPW) issue_piece(d_src + (Q / PPW) * CH, d_dst + (Q / PPW) * CH, std::integral_constant<int, Q % PPW>());
+    };
+    auto issue_pair = [&]() __attribute__((always_inline)) {
+        pair_begin();
+        issue_q(std::integral_constant<int, 0>());
+        issue_q(std::integral_constant<int, 1>());
+        issue_q(std::integral_constant<int, 2>());
+        issue_q(std::integral_constant<int, 3>());
+    };
+    // behind MFMA f of the pair's first chunk (DMA = 1): one piece behind MFMAs 1, 3, 5, 7
+    auto dma_behind = [&](int f, auto dma_c) __attribute__((always_inline)) {
+        if constexpr (decltype(dma_c)::value != 0) {
+            if (f == 1) issue_q(std::integral_constant<int, 0>());
+            if (f == 3) issue_q(std::integral_constant<int, 1>());
+            if (f == 5) issue_q(std::integral_constant<int, 2>());
+            if (f == 7) issue_q(std::integral_constant<int, 3>());
+        }
+    };
     int slot_c = 0;  // slot of the next chunk this wave computes
     // Head of a PAIR of chunks: one wait + one workgroup barrier per 2 CHF MFMAs of a wave.  Both chunks were requested a whole pair ago (EXTRA =
     // vector-memory operations the wave has issued since, which may stay in flight); every wave has left the previous pair, whose two slots
     // take the next pair's requests.
-    auto pair_head = [&](auto extra_c) __attribute__((always_inline)) {
+    auto pair_head = [&](auto extra_c) __attribute__((always_inline)) {  // (the requests follow inside the first chunk: dma_behind)
         wait_vmcnt<decltype(extra_c)::value>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue_pair();
+        pair_begin();
     };
     auto next_slot = [&]() __attribute__((always_inline)) { slot_c = (slot_c + 1) & (NS - 1); };
     auto frag = [&](const char *sb, int f) __attribute__((always_inline)) { return as_bf16x8(*reinterpret_cast<const u32x4 *>(sb + f * 1024)); };
@@ -210,7 +228,13 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
     for (int rd = 0; rd < rounds; ++rd) {
         const int wt = w0 + rd * NW + wave;
         if (wt >= w1) {  // (uniform) no tile for this wave in the last round: pass the round's barriers, keep requesting
-            for (int c = 0; c < NPAIR; ++c) pair_head(E0);
+            for (int c = 0; c < NPAIR; ++c) {
+                pair_head(E0);
+                issue_q(std::integral_constant<int, 0>());
+                issue_q(std::integral_constant<int, 1>());
+                issue_q(std::integral_constant<int, 2>());
+                issue_q(std::integral_constant<int, 3>());
+            }
             continue;
         }
         const int n_wave = wt * 32;
@@ -237,6 +261,7 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
                 for (int f = 0; f < CHF; ++f) {
                     out[f >> 1] = mfma32(fr[f % PD], zreg[2 * c + (f & 1)], out[f >> 1]);
                     if (f + PD < CHF) fr[f % PD] = frag(sb, f + PD);
+                    if ((c & 1) == 0) dma_behind(f, std::integral_constant<int, 1>());
                 }
                 next_slot();
                 __builtin_amdgcn_sched_barrier(0);  // (one chunk's fragments and temporaries live at a time)
@@ -278,7 +303,7 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
             }
         };
         // U(j): the chain of block j from its bias into `uc`; behind it the GELU words [first_word, first_word + CHF / stride) of `ue` -> gd
-        auto step_up = [&](f32x16 &uc, int j, int stride, int first_word, const f32x16 &ue, u32x4 (&gd)[2], auto gelu_c) __attribute__((always_inline)) {
+        auto step_up = [&](f32x16 &uc, int j, int stride, int first_word, const f32x16 &ue, u32x4 (&gd)[2], auto gelu_c, auto dma_c) __attribute__((always_inline)) {
             constexpr bool DO_GELU = decltype(gelu_c)::value != 0;
             {
                 unsigned ba = b1_base + 16u * (unsigned)(fresh_lane() >> 5) + 128u * (unsigned)j;
@@ -307,13 +332,14 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
                     if (ks + PD < KS) bfr[(ks - KR) % PD] = frag(ab, ks - KR + PD);
                 }
                 if (ks + PD < KS) fr[ks % PD] = frag(sb, ks + PD);
+                dma_behind(ks, dma_c);
                 if (DO_GELU) gelu_behind(ks, stride, first_word, ue, gd);
             }
             next_slot();
             __builtin_amdgcn_sched_barrier(0);
         };
         // D(j): out^T += W2m(block j) gelu(u_j)^T with the packed words of `gw` as B fragments; behind it GELU words of `ue` -> gd
-        auto step_down = [&](const u32x4 (&gw)[2], int stride, int first_word, const f32x16 &ue, u32x4 (&gd)[2], auto gelu_c) __attribute__((always_inline)) {
+        auto step_down = [&](const u32x4 (&gw)[2], int stride, int first_word, const f32x16 &ue, u32x4 (&gd)[2], auto gelu_c, auto dma_c) __attribute__((always_inline)) {
             constexpr bool DO_GELU = decltype(gelu_c)::value != 0;
             const char *sb = smem + slot_c * CH + fresh_lane() * 16;
             bf16x8 fr[PD];
@@ -323,6 +349,7 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
             for (int f = 0; f < CHF; ++f) {
                 out[f >> 1] = mfma32(fr[f % PD], as_bf16x8(gw[f & 1]), out[f >> 1]);
                 if (f + PD < CHF) fr[f % PD] = frag(sb, f + PD);
+                dma_behind(f, dma_c);
                 if (DO_GELU) gelu_behind(f, stride, first_word, ue, gd);
             }
             next_slot();
@@ -333,30 +360,30 @@ __global__ void __launch_bounds__(512, 2) k_tail(TailArgs g) {
         constexpr int S8 = CHF / 8 > 0 ? CHF / 8 : 1, S4 = CHF / 4;  // one pair behind every S8-th MFMA: 8 words per chunk; every S4-th: 4 words
         // pair (U0, U1): GELU(0) whole behind U(1)
         pair_head(E0);
-        step_up(up0, 0, 1, 0, up1, gwE, I0);
-        step_up(up1, 1, S8, 0, up0, gwE, I1);
+        step_up(up0, 0, 1, 0, up1, gwE, I0, I1);
+        step_up(up1, 1, S8, 0, up0, gwE, I1, I0);
         // pairs (D(j - 1), U(j + 1)), j = 1 .. MB - 2: GELU(j) behind both, half each
         for (int j = 1; j + 1 <= MB - 2; j += 2) {  // (MB is even: host-checked - no parity branches, whose merged register state hipcc spills)
             pair_head(E0);
-            step_down(gwE, S4, 0, up1, gwO, I1);         // D(j - 1) | GELU(j) words 0-3      (j odd)
-            step_up(up0, j + 1, S4, 4, up1, gwO, I1);    // U(j + 1) | GELU(j) words 4-7
+            step_down(gwE, S4, 0, up1, gwO, I1, I1);     // D(j - 1) | GELU(j) words 0-3      (j odd)
+            step_up(up0, j + 1, S4, 4, up1, gwO, I1, I0);  // U(j + 1) | GELU(j) words 4-7
             pair_head(E0);
-            step_down(gwO, S4, 0, up0, gwE, I1);         // D(j)     | GELU(j + 1) words 0-3
-            step_up(up1, j + 2, S4, 4, up0, gwE, I1);    // U(j + 2) | GELU(j + 1) words 4-7
+            step_down(gwO, S4, 0, up0, gwE, I1, I1);     // D(j)     | GELU(j + 1) words 0-3
+            step_up(up1, j + 2, S4, 4, up0, gwE, I1, I0);  // U(j + 2) | GELU(j + 1) words 4-7
         }
         // pair (D(MB - 2), D(MB - 1)): GELU(MB - 1) (odd block: up1) whole behind D(MB - 2).  Between the two the h rows of the first NPF feature
         // tiles are requested, behind the registers of the accumulator tiles and one fragment pair (dead now), so that they arrive under the last
         // chain.  Rows beyond N are read (h is padded to whole 256-row tiles), never written.
         f32x4_t hv[NPF][4];
         pair_head(E0);
-        step_down(gwE, S8, 0, up1, gwO, I1);
+        step_down(gwE, S8, 0, up1, gwO, I1, I1);
         {
             const int l = fresh_lane();
             const unsigned hoff0 = (unsigned)(n_wave + (l >> 3)) * (unsigned)(4 * D) + 16u * (l & 7);
 #pragma unroll
             for (int k = 0; k < NPF; ++k) load_h(hv[k], hoff0, k);
         }
-        step_down(gwO, 1, 0, up1, gwE, I0);
+        step_down(gwO, 1, 0, up1, gwE, I0, I0);
 
         // ---- epilogue: h += gate (out + b2); LayerNorm + modulate of the next sub-block ----
         const int le = fresh_lane(), chunk = le & 7, rowi = le >> 3, r = le & 31, hf = le >> 5;

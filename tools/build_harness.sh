@@ -19,6 +19,13 @@ lin1|lin2)
     sed -i 's#"common.hip.h"#"../../lam_slide_amd/csrc/common.hip.h"#' "$root/tools/_exp/k_${which}_probed.hip.h"
     flags+=("-D$(echo $which | tr a-z A-Z)_PROBED")
   fi ;;
+tail)
+  if printf '%s\n' "${flags[@]:-}" | grep -q "TAIL_STAMP"; then  # cycle sums per phase (z rows / O phase / a rows / mlp / epilogue)
+    cp "$root/lam_slide_amd/csrc/k_tail.hip.h" "$root/tools/_exp/k_tail_stamped.hip.h"
+    patch -s "$root/tools/_exp/k_tail_stamped.hip.h" < "$root/tools/experiments/tail_stamps.patch"
+    sed -i 's#"common.hip.h"#"../../lam_slide_amd/csrc/common.hip.h"#' "$root/tools/_exp/k_tail_stamped.hip.h"
+    flags+=("-DTAIL_STAMPED")
+  fi ;;
 esac
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -Wno-unused-value -I"$root/tools" "${flags[@]:-}" "$root/tools/${which}_harness.hip" -o "$root/tools/_exp/$name"
 echo "built tools/_exp/$name"

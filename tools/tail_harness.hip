@@ -11,7 +11,11 @@
 #include <algorithm>
 #include <vector>
 
+#ifdef TAIL_STAMPED  // tools/build_harness.sh tail <name> -DTAIL_STAMP: the product kernel + tools/experiments/tail_stamps.patch (s_memtime sums per phase)
+#include "_exp/k_tail_stamped.hip.h"
+#else
 #include "../lam_slide_amd/csrc/k_tail.hip.h"
+#endif
 
 #define CK(x)                                                                  \
     do {                                                                       \
@@ -85,7 +89,15 @@ void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
     const int ntile = (N + 255) / 256;
     int wgs = 256;
     const int grid = grid_arg > 0 ? grid_arg : std::min((N + 31) / 32, wgs);
+#ifdef TAIL_STAMPED
+    unsigned long long *stamps;
+    CK(hipMalloc(&stamps, 256 * 8 * 8 * 8));
+    CK(hipMemset(stamps, 0, 256 * 8 * 8 * 8));
+#endif
     TailArgs ta{wt, A, Z, b1 + 3 * HHD, b2, gate, h, A2, nshift, nscale, N, M, K2, mod_stride, tpt, magic_of(tpt)};
+#ifdef TAIL_STAMPED
+    ta.stamps = stamps;
+#endif
     printf("  lds %zu bytes, grid %d x %d threads, %d tiles of %d tokens, stream %.2f MB\n", lds, grid, NW * 64, ntile, 256, C::stream_bytes(M) / 1e6);
     const int reps = getenv("TAIL_REPS") ? atoi(getenv("TAIL_REPS")) : 1;
     for (int rep = 0; rep < reps; ++rep) {
@@ -161,6 +173,21 @@ void run_case(int N, int M, int tpt, int shared, int iters, int grid_arg) {
         printf("  round %d: %.4f ms/launch = %.1f us (%.0f TF/s, %.3f of 2.5 PF)\n", round, ms / iters, 1e3 * ms / iters, flop / (ms / iters * 1e-3) * 1e-12,
                flop / (ms / iters * 1e-3) * 1e-12 / 2500.0);
     }
+#ifdef TAIL_STAMPED
+    {   // one more launch, then the stamps of the last launch: cycles per round and phase
+        CK(hipMemset(stamps, 0, 256 * 8 * 8 * 8));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, 0, ta);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hs(256 * 8 * 8);
+        CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        for (int wg : {0, 77, 200})
+            for (int w : {0, 4, 7}) {
+                const unsigned long long *c = &hs[((size_t)wg * 8 + w) * 8];
+                if (c[5]) printf("  wg %3d wave %d: %llu rounds; per round (shader cycles by s_memtime): z rows %.0f, z + O phase %.0f, a rows + transposition %.0f, mlp %.0f, epilogue %.0f\n", wg, w, c[5],
+                                 (double)c[0] / c[5], (double)c[1] / c[5], (double)c[2] / c[5], (double)c[3] / c[5], (double)c[4] / c[5]);
+            }
+    }
+#endif
     hipFree(W1); hipFree(W2); hipFree(A); hipFree(A2); hipFree(Z); hipFree(wt); hipFree(b1); hipFree(b2); hipFree(mods); hipFree(h);
 }
 
