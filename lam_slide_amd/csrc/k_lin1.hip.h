@@ -58,6 +58,9 @@ struct Lin1Args {
 #ifndef LIN1_B2
 #define LIN1_B2 1
 #endif
+#ifndef LIN1_B2_KMAX
+#define LIN1_B2_KMAX 256  // widest K with the paired form
+#endif
 
 template <int HDP, int K, int NW = 8>
 struct Lin1Cfg {
@@ -70,7 +73,7 @@ struct Lin1Cfg {
     // k-step ks is one per-lane base + the immediate 32 ks.
     static constexpr int PITCH = ROWB + 16;
     static constexpr int BLK = 32 * PITCH;              // one weight block
-    static constexpr int NS = (LIN1_B2 && K <= 256) ? 4 : 3;  // ring slots
+    static constexpr int NS = (LIN1_B2 && K <= LIN1_B2_KMAX) ? 4 : 3;  // ring slots
     static constexpr int RING = NS * BLK;
     static_assert(NW == 8 || NW == 4, "two waves per SIMD (256-token tiles) or one (128-token tiles)");
     static constexpr int TT = 32 * NW;                  // tokens per tile
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_linear1_ts(Lin1Args g) {
     // flight: no head waits for the acknowledgement of a store issued less than a step ago.  Extra younger operations only make a
     // counted wait conservative, never wrong.  Then the workgroup barrier: every wave's pieces have landed and every wave has left the
     // previous block, whose slot is free for the block two ahead.
-    constexpr bool B2 = LIN1_B2 != 0 && K <= 256;
+    constexpr bool B2 = LIN1_B2 != 0 && K <= LIN1_B2_KMAX;
     auto step_head = [&](auto flushed_c) __attribute__((always_inline)) {
         if (B2) {  // (head of a pair of blocks: both were requested two steps ago, behind them only the previous step's slab stores)
             if (decltype(flushed_c)::value) wait_vmcnt<PPW>();
