@@ -789,6 +789,53 @@ def test_f11_real_pedestrian_k_sample_evaluation_on_device(golden, dev):
     parity("f11.fde", rel_l2(fdes.cpu(), f["fdes"]), 5e-4)
 
 
+def test_f12_real_nba_k_sample_evaluation_on_device(golden, dev):
+    """F12: what the reference's REAL NBA CondWrapper produced in the build container - `prepare_batch` (second_stage/nba.py:254-263) and
+    the `test_step` loop with the class defaults K = 60 / num_runs = 20 (:205-225, :229) - against the drop-in on the device at the NBA
+    shape (T = 20, L = 8, hidden 256, 16 heads, mlp 4, class vector: the general kernels, per-trajectory modulation rows): Stage1Encoder ->
+    ONE fused 60-sample call -> Stage1Decoder -> best-of-the-first-20 ADE / FDE, in the default and in the tail decomposition."""
+    from lam_slide_amd import CreateTransport, SecondStageSampler, Stage1Decoder, Stage1Encoder
+    from lam_slide_amd.sampling import best_of_k_errors
+    from oracle import latent_net
+    f = golden("f12_nba_k.npz")
+    B, T, A, L, K, c0, c1, n, R = (int(v) for v in f["meta"])
+    sh = shape_from(f.group("shape"))
+    s1 = f.group("stage1")
+    enc = Stage1Encoder(s1, num_head_cross=8, dim_head_cross=16, num_head_latent=2, dim_head_latent=16)
+    dec = Stage1Decoder(s1, num_head_latent=2, dim_head_latent=16, num_head_cross=8, dim_head_cross=16)
+    flat = lambda t: t.reshape(-1, *t.shape[2:])  # noqa: E731
+    pos = f["pos"].clone()
+    pos[:, c1:] = 0  # (the reference hides the future frames from the encoder: :188-189)
+    lat = enc.encode(flat(pos @ f["lift"]).to(dev), flat(f["entities"]).to(dev), flat(f["attention_mask"]).to(dev)).reshape(B, T, L, 32)
+    y = f["embedding"].to(dev)[f["cond_scene"].long().to(dev)]  # CondWrapper.prepare_batch
+    assert torch.equal(y.cpu(), f["y"])
+    noises = torch.randn(K, B, T, L, 32, generator=torch.Generator().manual_seed(int(f["noise_seed"]))).to(dev)
+    ent = flat(f["entities"]).to(dev)
+    kept = [int(k) for k in f["kept"]]
+    for tail in (False, True):
+        net = build_net(sh, latent_net.random_params(sh, seed=int(f["weight_seed"])), dev)
+        if tail:
+            net.set_tail(True)
+        drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(c0, c1), mask_cond_mean=True,
+                                 sampling_kwargs={"sampling_method": "euler", "num_steps": n})
+        seen = {}
+
+        def decode(z):  # [K*B, T, L, C] -> [K*B, T, A, 3]
+            seen["final"] = z
+            p = dec.decode(z.reshape(-1, L, 32), ent.repeat(z.shape[0] // B, 1))
+            seen["pos"] = p.reshape(z.shape[0], T, A, 3)
+            return seen["pos"]
+
+        ades, fdes = best_of_k_errors(drv, lat, f["true_future"].to(dev), K, decode, agent_mask=f["attention_mask"][:, -1].to(dev), y=y,
+                                      inits=noises, num_runs=R)
+        assert drv.last_sampler.last_path == "fused" and net.tail == tail
+        tag = "f12.tail" if tail else "f12"
+        parity(tag + ".finals", rel_l2(seen["final"].reshape(K, B, T, L, 32)[kept].cpu(), f["finals"]), 1e-3)
+        parity(tag + ".positions", rel_l2(seen["pos"].reshape(K, B, T, A, 3)[kept].cpu(), f["positions"]), 5e-4)
+        parity(tag + ".ade", rel_l2(ades.cpu(), f["ades"]), 5e-4)
+        parity(tag + ".fde", rel_l2(fdes.cpu(), f["fdes"]), 5e-4)
+
+
 def test_graph_replay_matches_eager_bits(dev):
     """LSL_GRAPH=2: repeated sampling calls with the same buffers are captured into a hipGraph on their second appearance and replayed
     afterwards; results must be the bits of the eager path, also when the INPUT VALUES change between replays (the graph reads through

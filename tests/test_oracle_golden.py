@@ -203,3 +203,37 @@ def test_f11_real_pedestrian_cond_wrapper_k_loop(golden):
     tgt = f["true_future"].permute(0, 2, 1, 3).reshape(B * A, T - c1, 3)[keep]
     ades, fdes = harness.compute_errors(traj, tgt)
     assert ades.shape == f["ades"].shape and rel_l2(ades, f["ades"]) < 5e-6 and rel_l2(fdes, f["fdes"]) < 5e-6
+
+
+def test_f12_real_nba_cond_wrapper_k_loop(golden):
+    """F12 = the reference's real NBA CondWrapper (second_stage/nba.py, built by its own __init__ from the reference YAMLs in the build
+    container; class defaults K = 60, num_runs = 20) at the NBA shape (T = 20, L = 8, hidden 256, 16 heads, mlp 4, class vector):
+    `prepare_batch` (:254-263) and the `test_step` loop (:205-225).  The oracle chain reproduces the conditioning, the kept samples' final
+    latents and decoded positions, and the ADE / FDE over the FIRST num_runs samples of the real agents (what `selected_traj` is, :229)."""
+    f = golden("f12_nba_k.npz")
+    B, T, A, L, K, c0, c1, n, R = (int(v) for v in f["meta"])
+    sh = shape_from(f.group("shape"))
+    sd = latent_net.random_params(sh, seed=int(f["weight_seed"]))
+    s1 = f.group("stage1")
+    flat = lambda t: t.reshape(B * T, *t.shape[2:])  # noqa: E731
+    y = f["embedding"][f["cond_scene"].long()]
+    assert torch.equal(y, f["y"])
+    noises = torch.randn(K, B, T, L, 32, generator=torch.Generator().manual_seed(int(f["noise_seed"])))
+    pos = f["pos"].clone()
+    pos[:, c1:] = 0  # test_step hides the future frames from the encoder (:188-189)
+    lat = harness.encode(s1, harness.EncoderShape(num_latents=L), flat(pos @ f["lift"]), flat(f["entities"]), flat(f["attention_mask"])).reshape(B, T, L, 32)
+    xc, mask = harness.setup_conditioning(lat, (c0, c1), True)
+    assert torch.equal(mask, f["mask"]) and rel_l2(xc[:, :c1], f["x_cond"][:, :c1]) < 2e-6
+    kept = [int(k) for k in f["kept"]]
+    need = sorted(set(range(R)) | set(kept))
+    fin = {k: harness.sample_latents(sd, sh, otr.Transport("GVP", "data"), noises[k], xc, mask, y, "ODE", {"sampling_method": "euler", "num_steps": n})
+           for k in need}
+    assert rel_l2(torch.stack([fin[k] for k in kept]), f["finals"]) < 5e-6
+    dec = lambda z: harness.decode(s1, harness.DecoderShape(), z.reshape(-1, L, 32), flat(f["entities"]).repeat(z.shape[0], 1)).reshape(z.shape[0], B, T, A, 3)  # noqa: E731
+    assert rel_l2(dec(torch.stack([fin[k] for k in kept])), f["positions"]) < 5e-6
+    positions = dec(torch.stack([fin[k] for k in range(R)]))
+    keep = f["attention_mask"][:, -1].reshape(-1).bool()
+    traj = positions[:, :, c1:].permute(1, 3, 0, 2, 4).reshape(B * A, R, T - c1, 3)[keep]
+    tgt = f["true_future"].permute(0, 2, 1, 3).reshape(B * A, T - c1, 3)[keep]
+    ades, fdes = harness.compute_errors(traj, tgt)
+    assert ades.shape == f["ades"].shape and rel_l2(ades, f["ades"]) < 5e-6 and rel_l2(fdes, f["fdes"]) < 5e-6

@@ -17,6 +17,7 @@ Fixture families:
   f7_encode.npz     frozen stage-1 Encoder + quant with a ragged entity mask (MD17 encoder shape, 48 latents)
   f8_decode_split.npz  DecoderQuerySplitter (peptide decoder: 1x1-conv latent extender), one latent<-query cross block, tanh GELU
   f11_pedestrian_k.npz  the reference's REAL pedestrian CondWrapper: prepare_batch (class vector y) and the K = 20 test_step loop (ADE / FDE)
+  f12_nba_k.npz         the reference's REAL NBA CondWrapper at the NBA shape: prepare_batch and the K = 60 / num_runs = 20 test_step loop
   f9_sample.npz     the reference's REAL LightningModule (second_stage/md17.py Wrapper built by its own __init__ from the reference YAML,
                     lightning_base.py sample / prepare_batch / setup_conditioning unchanged; tools/ref_env.py supplies the Lightning / Hydra
                     stand-ins): stage-1 inputs -> encode -> conditioning -> 5 Euler updates -> decode, with the initial noise fixed
@@ -597,7 +598,69 @@ def f11():
         meta=np.array([B, T, A, L, K, F["cond_idx"][0], F["cond_idx"][1], F["num_steps"]]), shape=shape_dict(sh))
 
 
+def f12():
+    """The NBA conditioned caller, REAL files: second_stage/nba.py CondWrapper built by its own __init__ from the reference YAMLs (class
+    defaults K = 60, num_runs = 20); `CondWrapper.prepare_batch` (:254-263) and the `test_step` loop (:205-225: K sequential sample() calls,
+    best-of-the-first-num_runs ADE / FDE over the real agents) executed UNCHANGED at the NBA shape (T = 20, L = 8, hidden 256, 16 heads,
+    mlp 4, class vector; depth 2).  The K initial noises are torch.randn of a stored seed (not stored themselves); of the K final states
+    and decoded positions the fixture keeps samples 0, num_runs - 1 and K - 1, of the errors everything."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_env
+    from lam_slide_amd import dropin
+    dropin.uninstall()
+    ns = ref_env.setup()
+    F = ref_env.F12
+    B, T, A, L, K, R = F["B"], F["T"], F["A"], F["L"], F["K"], F["num_runs"]
+    lift = torch.randn(3, 128, generator=torch.Generator().manual_seed(40)) * 0.5
+    first, first_cls = ref_env.build_first_stage(ns, seed=41, num_latents=L, lift=lift)
+    w = ref_env.build_nba_wrapper(ns, first, first_cls)
+    w.eval()
+    sh = latent_net.NetShape(**F["backbone"])
+    wseed, nseed = 44, 45
+    w.backbone.load_state_dict(latent_net.random_params(sh, seed=wseed))
+    batch = ref_env.f12_batch()
+    true_future = batch["pos"][:, F["cond_idx"][1]:].clone()
+    noises = torch.randn(K, B, T, L, 32, generator=torch.Generator().manual_seed(nseed))
+    pb = w.prepare_batch({k: v.clone() for k, v in batch.items()})
+    y, xc, mask = pb["model_kwargs"]["y"], pb["model_kwargs"]["x_cond"], pb["model_kwargs"]["x_cond_mask"]
+    assert torch.equal(y, w.vec_in_embedding.weight[batch["cond_scene"]])
+    finals, poss = [], []
+    real_decode = w.decode
+
+    def tap(latents, entities):  # (the same layout hand-over as F11: decode() returns [B, T, A, D], test_step rearranges "(B T) L D": nba.py:145-148, :207)
+        out = real_decode(latents, entities)
+        finals.append(latents.clone().reshape(B, T, L, 32))
+        poss.append(out["pos"].clone())
+        return {"pos": out["pos"].reshape(B * T, A, -1)}
+
+    w.decode = tap
+    w.on_test_epoch_start()
+    with ref_env.randn_like_sequence(noises) as seq:
+        w.test_step({k: v.clone() for k, v in batch.items()}, 0)
+    assert seq.i == K and len(finals) == K
+    ades, fdes = torch.cat(w.test_step_outputs["score"]["ades"]), torch.cat(w.test_step_outputs["score"]["fdes"])
+    finals, poss = torch.stack(finals), torch.stack(poss)
+    s1 = {k: v.clone() for k, v in first.backbone.state_dict().items()}
+    sd = latent_net.random_params(sh, seed=wseed)
+    flat = lambda t: t.reshape(B * T, *t.shape[2:])  # noqa: E731
+    zeroed = batch["pos"].clone()
+    zeroed[:, F["cond_idx"][1]:] = 0  # (test_step zeroes the future frames before sampling: nba.py:188-189)
+    o_lat = harness.encode(s1, harness.EncoderShape(num_latents=L), flat(zeroed @ lift), flat(batch["entities"]), flat(batch["attention_mask"])).reshape(B, T, L, 32)
+    oxc, omask = harness.setup_conditioning(o_lat, tuple(F["cond_idx"]), True)
+    keep_k = [0, R - 1, K - 1]
+    o_final = torch.stack([harness.sample_latents(sd, sh, otr.Transport("GVP", "data"), noises[k], oxc, omask, y, "ODE",
+                                                  {"sampling_method": "euler", "num_steps": F["num_steps"]}) for k in keep_k])
+    o_pos = harness.decode(s1, harness.DecoderShape(), o_final.reshape(len(keep_k) * B * T, L, 32), flat(batch["entities"]).repeat(len(keep_k), 1)).reshape(len(keep_k), B, T, A, 3)
+    print(f"F12 real NBA CondWrapper: conditioning {rel(oxc[:, :F['cond_idx'][1]], xc[:, :F['cond_idx'][1]]):.2e} finals {rel(o_final, finals[keep_k]):.2e} "
+          f"positions {rel(o_pos, poss[keep_k]):.2e}; ADE {ades.mean():.4f} FDE {fdes.mean():.4f} over {ades.numel()} agents, K = {K}, first {R} count")
+    assert rel(o_final, finals[keep_k]) < 1e-5 and rel(o_pos, poss[keep_k]) < 1e-5 and torch.equal(omask, mask)
+    npz("f12_nba_k.npz", stage1=s1, lift=lift, weight_seed=np.array(wseed), noise_seed=np.array(nseed), embedding=w.vec_in_embedding.weight.detach().clone(),
+        pos=batch["pos"], entities=batch["entities"], attention_mask=batch["attention_mask"], cond_scene=batch["cond_scene"],
+        y=y, x_cond=xc, mask=mask, kept=np.array(keep_k), finals=finals[keep_k], positions=poss[keep_k], ades=ades, fdes=fdes, true_future=true_future,
+        meta=np.array([B, T, A, L, K, F["cond_idx"][0], F["cond_idx"][1], F["num_steps"], R]), shape=shape_dict(sh))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
     for w in which:
         globals()[w]()

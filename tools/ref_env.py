@@ -169,6 +169,7 @@ def setup():
             return getattr(importlib.import_module(module_name), class_name)
 
         mod("src.utils.utils", load_class=load_class)
+        mod("src.datasets.nba", dataset_cond_indices={"score": 0, "rebound": 1})  # (datasets/nba.py:26-29; the module itself needs easydict / joblib)
         mod("src.datasets.md17", dataset_cond_indices={n: i for i, n in enumerate(
             ("aspirin", "benzene", "ethanol", "malonaldehyde", "naphthalene", "salicylic", "toluene", "uracil"))})
         _done = True
@@ -311,6 +312,48 @@ def f11_batch(seed=33):
     return {"pos": torch.randn(B, T, A, F9["dim_input"], generator=g),
             "entities": torch.stack([torch.randperm(F9["n_entities"], generator=g)[:A] for _ in range(B)])[:, None].expand(B, T, A).contiguous(),
             "attention_mask": am, "cond_scene": torch.tensor([4, 0, 2])}
+
+
+# ---- F12: the reference's real NBA CondWrapper (second_stage/nba.py): prepare_batch and the K = 60 / num_runs = 20 test_step ----
+
+F12 = dict(B=2, T=20, A=5, L=8, K=60, num_runs=20, cond_idx=[0, 8], num_steps=6, n_classes=2, vec_in_dim=256,
+           backbone=dict(depth=2, in_dim=32, hidden_size=256, mlp_ratio=4, num_heads=16, normalize=True, vec_in_dim=256))
+
+
+def build_nba_wrapper(ns, first_stage, first_stage_cls, seed=42):
+    """second_stage/nba.py CondWrapper, constructed by ITS OWN __init__ from the reference's own YAML blocks (configs/model/nba/second-stage.yaml
+    + second-stage_cond.yaml) with the F12 sizes (true T = 20, L = 8, hidden 256, 16 heads, mlp 4; depth 2 instead of 6).  K and num_runs are
+    not in the YAML: the class defaults (60 / 20, nba.py:33-35) apply."""
+    import yaml
+    nba = importlib.import_module("src.models.composites.second_stage.nba")
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs/model/nba/second-stage.yaml")))
+    cond = yaml.safe_load(open(os.path.join(REF, "configs/model/nba/second-stage_cond.yaml")))
+    for k in ("_target_", "_recursive_", "defaults"):
+        cfg.pop(k, None)
+    assert cond["_target_"].endswith("nba.CondWrapper") and "K" not in cfg and "num_runs" not in cfg and cfg["cond_idx"] == F12["cond_idx"]
+    cfg.update(compile=False, num_timesteps=F12["T"], ema=None, scheduler=None, n_classes=cond["n_classes"], vec_in_dim=cond["vec_in_dim"],
+               sampling_method="ODE", sampling_kwargs={"sampling_method": "euler", "num_steps": F12["num_steps"]})
+    cfg["backbone"] = dict(cfg["backbone"], **F12["backbone"])
+    key = f"f12-stage1-{id(first_stage)}"
+    _STAGE1[key] = first_stage
+    mod_name = "_lsl_f12_first_stage"
+    sys.modules.setdefault(mod_name, types.ModuleType(mod_name)).FirstStage = first_stage_cls
+    cfg["first_stage_model"] = {"class_name": f"{mod_name}.FirstStage", "path": key}
+    torch.manual_seed(seed)
+    w = nba.CondWrapper(**{k: (AttrDict(v) if isinstance(v, dict) else v) for k, v in cfg.items()})
+    assert w.hparams.K == F12["K"] and w.hparams.num_runs == F12["num_runs"]
+    w.trainer = types.SimpleNamespace(datamodule=types.SimpleNamespace(dataloader_names=lambda idx: "score"))
+    return w
+
+
+def f12_batch(seed=43):
+    g = torch.Generator().manual_seed(seed)
+    B, T, A = F12["B"], F12["T"], F12["A"]
+    am = torch.ones(B, T, A, dtype=torch.bool)
+    am[1, :, 4] = False  # a padded agent: dropped from the error statistics (nba.py:184-186)
+    return {"pos": torch.randn(B, T, A, 3, generator=g),
+            "entities": torch.stack([torch.randperm(F9["n_entities"], generator=g)[:A] for _ in range(B)])[:, None].expand(B, T, A).contiguous(),
+            "attention_mask": am, "cond_scene": torch.tensor([1, 0])}
 
 
 class randn_like_sequence:
