@@ -131,8 +131,9 @@ def _cross_block(p, pre, x, ctx, heads, dim_head, ds, mask=None):
     return _ff(p, pre + ".ff", x, ds.act) + x
 
 
-def decode(p: Dict[str, Tensor], ds: DecoderShape, z: Tensor, entities: Tensor) -> Tensor:
-    """z: [F, L, dim_latent] final latents of F frames; entities: [F, A] int -> positions [F, A, out_pos].
+def decode(p: Dict[str, Tensor], ds: DecoderShape, z: Tensor, entities: Tensor, output: str = "pos") -> Tensor:
+    """z: [F, L, dim_latent] final latents of F frames; entities: [F, A] int -> positions [F, A, out_pos] (`output`: the name of the decoder head,
+    decoder.py:62-71 - "pos" for the trajectory models, "atom14_pos" (42 wide) for the peptide first stage).
 
     Parameter names: ``post_quant.1.*`` (lightning_base.py:28-31) and ``decoder.*`` (decoder.py:31-80).
     The entity table is used with rows clipped to unit norm, which is what nn.Embedding(max_norm=1)
@@ -152,8 +153,8 @@ def decode(p: Dict[str, Tensor], ds: DecoderShape, z: Tensor, entities: Tensor) 
         y = torch.nn.functional.linear(lat, w, b)  # [F, L, D*N], channel = d * N + n
         lat = y.reshape(y.shape[0], y.shape[1], lat.shape[-1], n_split).permute(0, 1, 3, 2).reshape(y.shape[0], y.shape[1] * n_split, lat.shape[-1])
     o = _cross_block(p, "decoder.output_block", q, lat, ds.num_head_cross, ds.dim_head_cross, ds)
-    o = _act(torch.nn.functional.linear(o, p["decoder.output_layers.pos.0.weight"], p["decoder.output_layers.pos.0.bias"]), ds.act)
-    return torch.nn.functional.linear(o, p["decoder.output_layers.pos.2.weight"], p["decoder.output_layers.pos.2.bias"])
+    o = _act(torch.nn.functional.linear(o, p[f"decoder.output_layers.{output}.0.weight"], p[f"decoder.output_layers.{output}.0.bias"]), ds.act)
+    return torch.nn.functional.linear(o, p[f"decoder.output_layers.{output}.2.weight"], p[f"decoder.output_layers.{output}.2.bias"])
 
 
 def rel_l2(a: Tensor, b: Tensor) -> float:

@@ -836,6 +836,40 @@ def test_f12_real_nba_k_sample_evaluation_on_device(golden, dev):
         parity(tag + ".fde", rel_l2(fdes.cpu(), f["fdes"]), 5e-4)
 
 
+def test_f13_real_peptide_wrapper_sample_on_device(golden, dev):
+    """F13: what the reference's REAL peptide second-stage Wrapper produced in the build container at T = 1000 (`encode`, the base class's
+    `sample`, `decode` to atom14 positions: second_stage/peptide.py:85-102, lightning_base.py:217-238) against the drop-in on the device:
+    Stage1Encoder (2 latents of 96, no entity mask) -> one fused sampling call at the peptide shape (T = 1000: chunked-key temporal attention
+    with the denominator column, packed L = 2 spatial attention, 24 -> 32 padded heads, the K2 = 2 048 linear2 tiling) -> Stage1Decoder with
+    the query splitter and the 42-wide atom14 head.  Compared on the frames the fixture keeps (every 8th)."""
+    from golden_inputs import peptide_frames
+    from lam_slide_amd import CreateTransport, SecondStageSampler, Stage1Decoder, Stage1Encoder
+    from oracle import latent_net
+    f = golden("f13_peptide.npz")
+    B, T, R, L, c0, c1, n = (int(v) for v in f["meta"])
+    st = int(f["frame_stride"])
+    sh = shape_from(f.group("shape"))
+    net = build_net(sh, latent_net.random_params(sh, seed=int(f["weight_seed"])), dev)
+    s1 = f.group("stage1")
+    enc = Stage1Encoder(s1, num_head_cross=2, dim_head_cross=16, num_head_latent=2, dim_head_latent=16)
+    dec = Stage1Decoder(s1, num_head_latent=2, dim_head_latent=16, num_head_cross=2, dim_head_cross=16, output="atom14_pos")
+    assert dec.num_split == 8 and dec.out_dim == 42
+    batch = peptide_frames(int(f["batch_seed"]), B, T, R)
+    flat = lambda t: t.reshape(-1, *t.shape[2:])  # noqa: E731
+    x = flat(batch["atom14_pos"].flatten(-2) @ f["lift"]).to(dev)
+    ent = flat(batch["entities"]).to(dev)
+    lat = enc.encode(x, ent, None).reshape(B, T, L, 96)
+    parity("f13.cond_latents", rel_l2(lat[:, :1].cpu(), f["cond_latents"]), 5e-4)
+    noise = torch.randn(B, T, L, 96, generator=torch.Generator().manual_seed(int(f["noise_seed"]))).to(dev)
+    drv = SecondStageSampler(net, CreateTransport("GVP", "data")(), cond_idx=(c0, c1), mask_cond_mean=True,
+                             sampling_kwargs={"sampling_method": "euler", "num_steps": n})
+    final = drv.sample_latents(lat, init=noise)
+    assert drv.last_sampler.last_path == "fused"
+    parity("f13.finals", rel_l2(final[:, ::st].cpu(), f["finals"]), 1e-3)
+    pos = dec.decode(final.reshape(B * T, L, 96), ent).reshape(B, T, R, 14, 3)
+    parity("f13.atom14_positions", rel_l2(pos[:, ::st].cpu(), f["positions"]), 1e-3)
+
+
 def test_graph_replay_matches_eager_bits(dev):
     """LSL_GRAPH=2: repeated sampling calls with the same buffers are captured into a hipGraph on their second appearance and replayed
     afterwards; results must be the bits of the eager path, also when the INPUT VALUES change between replays (the graph reads through

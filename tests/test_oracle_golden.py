@@ -237,3 +237,32 @@ def test_f12_real_nba_cond_wrapper_k_loop(golden):
     tgt = f["true_future"].permute(0, 2, 1, 3).reshape(B * A, T - c1, 3)[keep]
     ades, fdes = harness.compute_errors(traj, tgt)
     assert ades.shape == f["ades"].shape and rel_l2(ades, f["ades"]) < 5e-6 and rel_l2(fdes, f["fdes"]) < 5e-6
+
+
+def test_f13_real_peptide_wrapper_sample(golden):
+    """F13 = the reference's real peptide second-stage Wrapper (second_stage/peptide.py, built by its own __init__ from the reference YAML in
+    the build container) at T = 1000: `encode` (:85-95), the base class's `sample` (lightning_base.py:217-238), `decode` to atom14 positions
+    (:97-102), over a first stage of the peptide sizes (2 latents of 96, DecoderQuerySplitter, atom14 head of 42).  The oracle chain
+    reproduces the conditioning frame, the final latents and the decoded positions on the kept frames (every 8th).  The full restatement at
+    T = 1000 takes ~ 20 s on the CPU."""
+    from golden_inputs import peptide_frames
+    f = golden("f13_peptide.npz")
+    B, T, R, L, c0, c1, n = (int(v) for v in f["meta"])
+    st = int(f["frame_stride"])
+    sh = shape_from(f.group("shape"))
+    sd = latent_net.random_params(sh, seed=int(f["weight_seed"]))
+    s1 = f.group("stage1")
+    batch = peptide_frames(int(f["batch_seed"]), B, T, R)
+    assert torch.equal(batch["atom14_pos"][:, :1], f["atom14_frame0"])
+    noise = torch.randn(B, T, L, 96, generator=torch.Generator().manual_seed(int(f["noise_seed"])))
+    flat = lambda t: t.reshape(B * T, *t.shape[2:])  # noqa: E731
+    es = harness.EncoderShape(dim_input=f["lift"].shape[1], dim_latent=96, num_latents=L, num_head_cross=2, num_head_latent=2)
+    ds = harness.DecoderShape(dim_latent=96, num_head_cross=2, num_head_latent=2)
+    lat = harness.encode(s1, es, flat(batch["atom14_pos"].flatten(-2) @ f["lift"]), flat(batch["entities"]), None).reshape(B, T, L, 96)
+    assert rel_l2(lat[:, :1], f["cond_latents"]) < 2e-6
+    xc, mask = harness.setup_conditioning(lat, (c0, c1), True)
+    assert rel_l2(xc[:, :1], f["x_cond_frame0"]) < 2e-6 and int(mask.sum()) == B * (c1 - c0) * L
+    final = harness.sample_latents(sd, sh, otr.Transport("GVP", "data"), noise, xc, mask, None, "ODE", {"sampling_method": "euler", "num_steps": n})
+    assert rel_l2(final[:, ::st], f["finals"]) < 5e-6
+    pos = harness.decode(s1, ds, final.reshape(B * T, L, 96), flat(batch["entities"]), output="atom14_pos").reshape(B, T, R, 14, 3)
+    assert rel_l2(pos[:, ::st], f["positions"]) < 5e-6

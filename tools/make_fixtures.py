@@ -17,6 +17,7 @@ Fixture families:
   f7_encode.npz     frozen stage-1 Encoder + quant with a ragged entity mask (MD17 encoder shape, 48 latents)
   f8_decode_split.npz  DecoderQuerySplitter (peptide decoder: 1x1-conv latent extender), one latent<-query cross block, tanh GELU
   f11_pedestrian_k.npz  the reference's REAL pedestrian CondWrapper: prepare_batch (class vector y) and the K = 20 test_step loop (ADE / FDE)
+  f13_peptide.npz       the reference's REAL peptide Wrapper at T = 1000: encode -> sample -> decode to atom14 positions
   f12_nba_k.npz         the reference's REAL NBA CondWrapper at the NBA shape: prepare_batch and the K = 60 / num_runs = 20 test_step loop
   f9_sample.npz     the reference's REAL LightningModule (second_stage/md17.py Wrapper built by its own __init__ from the reference YAML,
                     lightning_base.py sample / prepare_batch / setup_conditioning unchanged; tools/ref_env.py supplies the Lightning / Hydra
@@ -660,7 +661,61 @@ def f12():
         meta=np.array([B, T, A, L, K, F["cond_idx"][0], F["cond_idx"][1], F["num_steps"], R]), shape=shape_dict(sh))
 
 
+def f13():
+    """The peptide caller, REAL files: second_stage/peptide.py Wrapper built by its own __init__ from the reference YAML at the true
+    T = 1000 (L = 2, C = 96, hidden 384, 16 heads of 24, mlp 4; depth 2), its `encode` (:85-95: keys atom14_pos / aatype / attention_mask /
+    entities, frames flattened), the base class's `sample` (lightning_base.py:217-238) and its `decode` (:97-102: "(B T) L (A D) -> B T L A D")
+    executed UNCHANGED over a first stage of the peptide sizes (2 latents of 96, DecoderQuerySplitter with 8 splits, atom14 head of 42).
+    The initial state is torch.randn of a stored seed; of the 1000 frames the fixture keeps every 8th (final latents and atom14 positions)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_env
+    from lam_slide_amd import dropin
+    dropin.uninstall()
+    ns = ref_env.setup()
+    F = ref_env.F13
+    B, T, R, L = F["B"], F["T"], F["R"], F["L"]
+    lift = torch.randn(42, F["dim_input"], generator=torch.Generator().manual_seed(50)) * 0.3
+    first, first_cls = ref_env.build_peptide_first_stage(ns, lift)
+    w = ref_env.build_peptide_wrapper(ns, first, first_cls)
+    w.eval()
+    sh = latent_net.NetShape(**F["backbone"])
+    wseed, nseed = 54, 55
+    w.backbone.load_state_dict(latent_net.random_params(sh, seed=wseed))
+    bseed = 53
+    batch = ref_env.f13_batch(bseed)
+    noise = torch.randn(B, T, L, 96, generator=torch.Generator().manual_seed(nseed))
+    seen = {}
+    real_decode = w.decode
+
+    def tap(latents, entities):
+        seen["final"] = latents.clone().reshape(B, T, L, 96)
+        return real_decode(latents, entities)
+
+    w.decode = tap
+    with ref_env.fixed_randn_like(noise):
+        out = w.sample({k: v.clone() for k, v in batch.items()})["atom14_pos"]
+    assert out.shape == (B, T, R, 14, 3)
+    pb = w.prepare_batch({k: v.clone() for k, v in batch.items()})
+    xc, mask = pb["model_kwargs"]["x_cond"], pb["model_kwargs"]["x_cond_mask"]
+    # the oracle chain on the same inputs
+    s1 = {k: v.clone() for k, v in first.backbone.state_dict().items()}
+    sd = latent_net.random_params(sh, seed=wseed)
+    flat = lambda t: t.reshape(B * T, *t.shape[2:])  # noqa: E731
+    es = harness.EncoderShape(dim_input=F["dim_input"], dim_latent=96, num_latents=L, num_head_cross=2, num_head_latent=2)
+    ds = harness.DecoderShape(dim_latent=96, num_head_cross=2, num_head_latent=2)
+    o_lat = harness.encode(s1, es, flat(batch["atom14_pos"].flatten(-2) @ lift), flat(batch["entities"]), None).reshape(B, T, L, 96)
+    oxc, omask = harness.setup_conditioning(o_lat, tuple(F["cond_idx"]), True)
+    o_final = harness.sample_latents(sd, sh, otr.Transport("GVP", "data"), noise, oxc, omask, None, "ODE", {"sampling_method": "euler", "num_steps": F["num_steps"]})
+    o_pos = harness.decode(s1, ds, o_final.reshape(B * T, L, 96), flat(batch["entities"]), output="atom14_pos").reshape(B, T, R, 14, 3)
+    print(f"F13 real peptide Wrapper (T = {T}): conditioning {rel(oxc, xc):.2e} finals {rel(o_final, seen['final']):.2e} atom14 positions {rel(o_pos, out):.2e}")
+    assert rel(o_final, seen["final"]) < 1e-5 and rel(o_pos, out) < 1e-5 and torch.equal(omask, mask)
+    keep = {k: v for k, v in s1.items() if "output_layers.aatype" not in k}  # (the residue-type head is not on this path)
+    npz("f13_peptide.npz", stage1=keep, lift=lift, weight_seed=np.array(wseed), noise_seed=np.array(nseed), batch_seed=np.array(bseed),
+        atom14_frame0=batch["atom14_pos"][:, :1].clone(), frame_stride=np.array(8), cond_latents=o_lat[:, :1].clone(), finals=seen["final"][:, ::8].clone(), positions=out[:, ::8].clone(),
+        x_cond_frame0=xc[:, :1].clone(), meta=np.array([B, T, R, L, F["cond_idx"][0], F["cond_idx"][1], F["num_steps"]]), shape=shape_dict(sh))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     for w in which:
         globals()[w]()

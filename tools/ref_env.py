@@ -169,6 +169,23 @@ def setup():
             return getattr(importlib.import_module(module_name), class_name)
 
         mod("src.utils.utils", load_class=load_class)
+        pkg.RankedLogger = importlib.import_module("src.utils.pylogger").RankedLogger  # (what src/utils/__init__.py re-exports; modules/geometry.py:6)
+        # second_stage/peptide.py imports geometry / residue constants (not on the sampling path): their third-party imports get shells
+        class PDBParser:  # (modules/protein.py:23; only instantiated when a PDB file is parsed)
+            def __init__(self, *a, **k):
+                raise RuntimeError("Bio.PDB is not available in the build container")
+
+        bio = mod("Bio")
+        bio.PDB = mod("Bio.PDB", PDBParser=PDBParser)
+
+        def map_structure(fn, st):  # (dm-tree's map_structure on the nested lists of utils/residue_constants.py:1065)
+            if isinstance(st, (list, tuple)):
+                return type(st)(map_structure(fn, x) for x in st)
+            if isinstance(st, dict):
+                return {k: map_structure(fn, v) for k, v in st.items()}
+            return fn(st)
+
+        mod("tree", map_structure=map_structure)
         mod("src.datasets.nba", dataset_cond_indices={"score": 0, "rebound": 1})  # (datasets/nba.py:26-29; the module itself needs easydict / joblib)
         mod("src.datasets.md17", dataset_cond_indices={n: i for i, n in enumerate(
             ("aspirin", "benzene", "ethanol", "malonaldehyde", "naphthalene", "salicylic", "toluene", "uracil"))})
@@ -354,6 +371,78 @@ def f12_batch(seed=43):
     return {"pos": torch.randn(B, T, A, 3, generator=g),
             "entities": torch.stack([torch.randperm(F9["n_entities"], generator=g)[:A] for _ in range(B)])[:, None].expand(B, T, A).contiguous(),
             "attention_mask": am, "cond_scene": torch.tensor([1, 0])}
+
+
+# ---- F13: the reference's real peptide second-stage Wrapper (second_stage/peptide.py) at the peptide shape ----
+
+F13 = dict(B=2, T=1000, R=4, L=2, cond_idx=[0, 1], num_steps=4, n_entities=32, dim_input=256, dim_latent=96,
+           backbone=dict(depth=2, in_dim=96, hidden_size=384, mlp_ratio=4, num_heads=16))
+
+
+def build_peptide_first_stage(ns, lift, seed=51):
+    """FirstStageLightningBase (real class) around a BackboneBase (real class) with the real Encoder / DecoderQuerySplitter at the sizes of
+    configs/model/peptide/first-stage.yaml (dim_input 256, dim_latent 96, 2 latents, 2 + 2 heads of 16, num_split 8, heads atom14_pos (42)
+    and aatype (20)); `encode` passes mask=None like first_stage/peptide.py:77-80; `prepare_inputs` - the residue / position embedding
+    of the first stage, not on this path - lifts the flattened atom14 coordinates with a fixed matrix stored in the fixture."""
+    from functools import partial
+    lb = ns.lightning_base
+    torch.manual_seed(seed)
+    emb = ns.entity.EntityEmbeddingOrthogonal(n_entiy_embeddings=F13["n_entities"], embedding_dim=128, max_norm=1)
+    act = partial(ns.torch_modules.GELU)
+    enc = ns.encoder.Encoder(dim_input=F13["dim_input"], dim_latent=F13["dim_latent"], dim_head_cross=16, dim_head_latent=16, num_latents=F13["L"],
+                             num_head_cross=2, num_head_latent=2, num_block_cross=1, num_block_attn=1, qk_norm=True, entity_embedding=emb, act=act)
+    dec = ns.decoder.DecoderQuerySplitter(outputs={"atom14_pos": 42, "aatype": 20}, dim_query=128, dim_latent=F13["dim_latent"], entity_embedding=emb,
+                                          dim_head_cross=16, dim_head_latent=16, num_head_cross=2, num_head_latent=2, num_block_cross=0,
+                                          num_block_attn=1, dropout_query=0.1, num_split=8, qk_norm=True, act=act)
+    with torch.no_grad():
+        emb.embedding.weight.mul_(torch.linspace(0.5, 1.8, F13["n_entities"])[:, None])
+
+    class Backbone(lb.BackboneBase):
+        def prepare_inputs(self, batch):
+            return batch["atom14_pos"].flatten(-2) @ lift
+
+        def encode(self, batch):  # (first_stage/peptide.py:77-80: no entity mask)
+            return self.quant(self.encoder(x=self.prepare_inputs(batch), entities=batch["entities"], mask=None))
+
+    class FirstStage(lb.FirstStageLightningBase):
+        def __init__(self, backbone):
+            super().__init__()
+            self.hparams.update(shift=0.0, scale=1.0, ema=None)
+            self.backbone = backbone
+
+        @classmethod
+        def load_from_checkpoint(cls, path, map_location=None):
+            return _STAGE1[path]  # (ema stays None: second_stage/peptide.py:53-54 skips load_ema_weights then)
+
+    return FirstStage(Backbone(dim_latent=F13["dim_latent"], encoder=enc, decoder=dec)), FirstStage
+
+
+def build_peptide_wrapper(ns, first_stage, first_stage_cls, seed=52):
+    """second_stage/peptide.py Wrapper, constructed by ITS OWN __init__ from the reference's own YAML block
+    (configs/model/peptide/second-stage.yaml: cond_idx [0, 1], mask_cond_mean, hidden 384, 16 heads of 24, mlp 4) with the true T = 1000;
+    depth 2 instead of 7."""
+    import yaml
+    pep = importlib.import_module("src.models.composites.second_stage.peptide")
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs/model/peptide/second-stage.yaml")))
+    for k in ("_target_", "_recursive_", "defaults"):
+        cfg.pop(k, None)
+    assert cfg["cond_idx"] == F13["cond_idx"] and cfg["mask_cond_mean"] is True and cfg["backbone"]["hidden_size"] == 384
+    cfg.update(n_timesteps=F13["T"], ema=None, scheduler=None, sampling_method="ODE",
+               sampling_kwargs={"sampling_method": "euler", "num_steps": F13["num_steps"]})
+    cfg["backbone"] = dict(cfg["backbone"], **F13["backbone"])
+    key = f"f13-stage1-{id(first_stage)}"
+    _STAGE1[key] = first_stage
+    mod_name = "_lsl_f13_first_stage"
+    sys.modules.setdefault(mod_name, types.ModuleType(mod_name)).FirstStage = first_stage_cls
+    cfg["first_stage_model"] = {"class_name": f"{mod_name}.FirstStage", "path": key}
+    torch.manual_seed(seed)
+    return pep.Wrapper(**{k: (AttrDict(v) if isinstance(v, dict) else v) for k, v in cfg.items()})
+
+
+def f13_batch(seed=53):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from golden_inputs import peptide_frames  # (shared with the tests: the fixture stores the seed, not the 1.3 MB of coordinates)
+    return peptide_frames(seed, F13["B"], F13["T"], F13["R"])
 
 
 class randn_like_sequence:
