@@ -378,7 +378,8 @@ void launch_attention_rows(const AttnArgs &a, hipStream_t st) {
 int attention_stream_mode(int S, int H) {  // 0: k_attention_rows / tiny / online, 1: stream SHORT, 2: stream LONG
     static const int on = env_int("LSL_ATTN_STREAM", 1);
     if (!on) return 0;
-    if (S > 128) return 2;  // (round 5: any length - keys in chunks of 256 through the two images, queries in groups of 8 tiles)
+    static const int long_min = tune_int("LSL_ATTN_LONG_MIN", 129);  // shortest axis on the LONG form
+    if (S >= long_min) return 2;  // (round 5: any length - keys in chunks of 256 through the two images, queries in groups of 8 tiles)
     if (S > 8 && S <= 32 && H % 8 == 0) return 1;
     return 0;
 }
