@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--tail", default="auto", choices=("auto", "on", "off"),
                     help="sub-block decomposition of the model handle (lam_slide_amd.LatentSIV3.set_tail): auto = the tail form for hidden-256 "
                          "models (NBA, md17_ref) at >= 131 072 tokens per GPU (where it is faster), the default form elsewhere")
+    ap.add_argument("--ln-fuse", default="auto", choices=("auto", "on", "off"),
+                    help="LayerNorm + modulate inside linear1's activation load (lam_slide_amd.LatentSIV3.set_ln_fuse): auto = on at >= 131 072 tokens "
+                         "per GPU (where it is faster) for handles that do not run the tail form, off elsewhere")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch and stage-1 legs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event passes (rocprofv3 runs: every launch of the trace then belongs to a warm-up or timed sampling call)")
@@ -258,6 +261,9 @@ def run_rank(args) -> int:
         tail_on = args.tail == "on" or (args.tail == "auto" and kw["hidden_size"] == 256 and B * T * L >= 131072)
         if tail_on or args.tail == "off":
             net.set_tail(tail_on)
+        lnf_on = args.ln_fuse == "on" or (args.ln_fuse == "auto" and not tail_on and B * T * L >= 131072)
+        if lnf_on or args.ln_fuse == "off":
+            net.set_ln_fuse(lnf_on)
         tr = CreateTransport("GVP", "data")()
         lat = torch.randn(B, T, L, kw["in_dim"], generator=g).to(dev)
         init = torch.randn(B, T, L, kw["in_dim"], generator=g).to(dev)
@@ -358,7 +364,7 @@ def run_rank(args) -> int:
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "build": None if stub else lib.lsl_build_info().decode(), "dtype": "bf16", "dtype_detail": "bf16 MFMA operands (linear1, linear2, attention), fp32 accumulators / residual state / small GEMMs",
         "data": "stub (launcher test, not a measurement)" if stub else "synthetic (seeded random weights and latents)",
-        "config": {"workload": args.workload, "tail": bool(not stub and net.tail), "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
+        "config": {"workload": args.workload, "tail": bool(not stub and net.tail), "ln_fuse": bool(not stub and net.ln_fuse), "T": T, "L": L, "C": kw["in_dim"], "D": D, "H": kw["num_heads"], "depth": kw["depth"],
                    "mlp_ratio": kw["mlp_ratio"], "sampler": method, "state_updates": n_evals, "batch_per_gpu": B,
                    "global_batch": B * world, "parallelism": f"batch-shard x{world}, 1 gather to rank 0 per step",
                    # rank r draws the device noise of global elements [r * stride, (r + 1) * stride): the slice of the unsharded stream
@@ -412,7 +418,7 @@ def run_rank(args) -> int:
         flops = {0: 2.0 * tok_total * D * (3 * D + (0 if tailed else M)),
                  1: 2.0 * tok_total * ((2 * M + D) * D if tailed else (D + M) * D),
                  2: 4.0 * tok_total * D * (L + T) / 2}.get(kid, 0.0) * block_evals
-        what = {0: "linear1 + bias / QK-norm / RoPE" + ("" if tailed else " / GELU") + " epilogue",
+        what = {0: ("LayerNorm + modulate on load + " if "LayerNorm" in name else "") + "linear1 + bias / QK-norm / RoPE" + ("" if tailed else " / GELU") + " epilogue",
                 1: "mlp up-projection + GELU + linear2 + gated residual + next LayerNorm" if tailed else "linear2 + gate / residual epilogue",
                 2: "attention"}.get(kid, f"kernel class {kid}")
         return f"{name} ({what})" if name else what, flops
@@ -436,7 +442,7 @@ def run_rank(args) -> int:
         kernel, for `profile_agrees`.  -> (bytes, source, trace_avg_us, trace_tokens_per_launch)"""
         fam = name.split("<")[0] if name else ""
         for tf, tj in traffic_files():
-            if key and key in tj and fam and tj[key].get("kernel", "").startswith(fam) and (("(q | k | v)" in name) == bool(tj.get("tail"))):
+            if key and key in tj and fam and tj[key].get("kernel", "").startswith(fam) and (("(q | k | v)" in name) == bool(tj.get("tail"))) and (("LayerNorm" in name) == bool(tj.get("ln_fuse"))):
                 scale = min(pass_size, B) * T * L / tj["tokens_per_launch"]
                 return int(tj[key]["bytes"] * scale), os.path.relpath(tf, ROOT), tj[key].get("avg_us"), tj["tokens_per_launch"]
         return None, None, None, None

@@ -35,8 +35,9 @@ extern "C" {
  * 3: lsl_rk_lincomb / lsl_rk_dense / lsl_rk_error_ratio exist (state arithmetic of the adaptive and fixed-grid Runge-Kutta samplers);
  *    no signature of version 2 changed.
  * 4: lsl_model_set_attention_mode exists (attention_linear, mmdit.py:58-72); nothing else changed.
- * 5: lsl_model_set_tail, lsl_model_tail, lsl_profile_kernel_name exist; no signature of version 4 changed. */
-#define LSL_VERSION 5
+ * 5: lsl_model_set_tail, lsl_model_tail, lsl_profile_kernel_name exist; no signature of version 4 changed.
+ * 6: lsl_model_set_ln_fuse, lsl_model_ln_fuse exist; no signature of version 5 changed. */
+#define LSL_VERSION 6
 
 typedef struct lsl_model lsl_model;
 
@@ -159,6 +160,16 @@ int lsl_model_set_attention_mode(lsl_model *m, int32_t mode);
  * Environment LSL_TAIL=1 / 0 sets the default of new handles / disables the form (A/B runs, tests). */
 int lsl_model_set_tail(lsl_model *m, int32_t on);
 int32_t lsl_model_tail(const lsl_model *m); /* 1 if the handle runs the tail form */
+
+/* LayerNorm + modulate of a sub-block (latent_si_v31.py:50-51,57-58) inside linear1's activation load.  0 (default): a LayerNorm kernel writes the
+ * bf16 operand `a`, linear1 reads it.  1: no LayerNorm launch - linear1 reads the fp32 residual stream, normalises and modulates its rows while
+ * it turns them into MFMA fragments (0.75 KB of HBM traffic per token and sub-block less at hidden 512; faster from about 10^5 tokens per pass,
+ * slower at small launches).  Wherever the token-stationary linear1 runs with its modulation rows in LDS (one shared row, or >= 128 / 256 tokens
+ * per trajectory at hidden <= 256 / above); elsewhere, and on handles in the tail form, the standalone kernel stays.  One more bf16 rounding of a
+ * deviation-sized value than the standalone kernel: results differ at the level of the bf16 operand (same error class against the fp32
+ * reference), so the choice belongs to the MODEL HANDLE, never to the batch.  Environment LSL_LN_FUSE=1 / 0: default of new handles / disabled. */
+int lsl_model_set_ln_fuse(lsl_model *m, int32_t on);
+int32_t lsl_model_ln_fuse(const lsl_model *m);
 
 /* Trajectories the library processes per pass for a call of this size (<= B). */
 int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L);

@@ -17,12 +17,12 @@ LIB_PATH = os.path.join(_HERE, "liblamslide_hip.so")
 SRC_DIR = os.path.join(_HERE, "csrc")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
-ABI_VERSION = 5  # LSL_VERSION of include/lsl_api.h this binding was written against
+ABI_VERSION = 6  # LSL_VERSION of include/lsl_api.h this binding was written against
 RK_SCRATCH_BYTES = 8192  # LSL_RK_SCRATCH_BYTES
 
 EXPORTED = (
     "lsl_version", "lsl_build_info", "lsl_last_error", "lsl_model_create", "lsl_model_set_weights", "lsl_model_destroy",
-    "lsl_model_set_chunk", "lsl_model_set_attention_mode", "lsl_model_set_tail", "lsl_model_tail", "lsl_profile_kernel_name", "lsl_pass_size", "lsl_sampler_path", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_sample_ex", "lsl_debug_block", "lsl_debug_taps", "lsl_debug_mods",
+    "lsl_model_set_chunk", "lsl_model_set_attention_mode", "lsl_model_set_tail", "lsl_model_tail", "lsl_model_set_ln_fuse", "lsl_model_ln_fuse", "lsl_profile_kernel_name", "lsl_pass_size", "lsl_sampler_path", "lsl_workspace_bytes", "lsl_forward", "lsl_sample", "lsl_sample_ex", "lsl_debug_block", "lsl_debug_taps", "lsl_debug_mods",
     "lsl_profile_enable", "lsl_profile_read", "lsl_randn", "lsl_rk_lincomb", "lsl_rk_dense", "lsl_rk_error_ratio",
     "lsl_decoder_create", "lsl_decoder_destroy", "lsl_decode_workspace_bytes", "lsl_decode",
     "lsl_encoder_create", "lsl_encoder_destroy", "lsl_encode_workspace_bytes", "lsl_encode",
@@ -133,6 +133,8 @@ def load() -> C.CDLL:
     lib.lsl_model_set_attention_mode.argtypes = [C.c_void_p, C.c_int32]
     lib.lsl_model_set_tail.argtypes = [C.c_void_p, C.c_int32]
     lib.lsl_model_tail.argtypes = [C.c_void_p]
+    lib.lsl_model_set_ln_fuse.argtypes = [C.c_void_p, C.c_int32]
+    lib.lsl_model_ln_fuse.argtypes = [C.c_void_p]
     lib.lsl_profile_kernel_name.argtypes = [C.c_void_p]
     lib.lsl_profile_kernel_name.restype = C.c_char_p
     lib.lsl_pass_size.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]

@@ -90,6 +90,14 @@ __device__ __forceinline__ float quad_xor2(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
 }
 
+// the sum over the 8 consecutive lanes 8 g .. 8 g + 7, in every one of them: two quad permutes and row_half_mirror (lane i <-> lane 7 - i of its
+// half row): three vector moves + adds, no LDS queue
+__device__ __forceinline__ float oct_sum(float v) {
+    v += quad_xor1(v);
+    v += quad_xor2(v);
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+}
+
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -58,6 +58,7 @@ struct lsl_model {
     bool attention_linear = false;  // lsl_model_set_attention_mode: attention_linear (mmdit.py:58-72) instead of softmax attention
     int chunk = 0;
     int HHD, F1, K2, MODW;
+    bool ln_fuse = false;  // LayerNorm + modulate inside linear1's activation load (k_lin1.hip.h LNF): lsl_model_set_ln_fuse, a property of the HANDLE
     bool tail = false;  // the back half of every sub-block runs k_tail (k_tail.hip.h): a property of the HANDLE (lsl_model_set_tail), never of the batch
     // hipGraph cache of lsl_sample: a call whose arguments (pointers, sizes, step table) repeat is captured once and replayed; the
     // small-batch configs are launch-bound (~700 launches of a few microseconds per sampling call)
@@ -92,6 +93,7 @@ struct Workspace {
     u16 *w2p;  // linear2 weights of every sub-block in the fragment order of k_linear2_ws (k_lin2_pack, once per call), or NULL
     u16 *wtail;  // tail models: the weight stream of every sub-block (k_tail_pack, once per call); wtail_stride elements apart
     size_t wtail_stride;
+    float2 *lnparts, *lnstat;  // ln_fuse handles: per-wave row statistics of k_linear2_ws<LNS> [D / 32][n rounded up to 256], per-token (rstd, -mean rstd)
     size_t bytes;
 };
 
@@ -136,6 +138,8 @@ Workspace carve(const lsl_model *m, char *base, int bc, int T, int L) {
     ws.w2p = !m->tail && linear2_ws_shape_ok((int)D, m->K2) ? (u16 *)take((size_t)2 * d.depth * D * m->K2 * 2) : nullptr;
     ws.wtail_stride = m->tail ? tail_stream_bytes(m) / 2 : 0;
     ws.wtail = m->tail ? (u16 *)take((size_t)2 * d.depth * ws.wtail_stride * 2) : nullptr;
+    ws.lnparts = m->ln_fuse && !m->tail ? (float2 *)take((size_t)(D / 32) * n_pad * sizeof(float2)) : nullptr;
+    ws.lnstat = m->ln_fuse && !m->tail ? (float2 *)take(n_pad * sizeof(float2)) : nullptr;
     ws.bytes = off;
     return ws;
 }

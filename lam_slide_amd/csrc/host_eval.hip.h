@@ -90,12 +90,21 @@ void run_tables(const lsl_model *m, const Workspace &ws, int T, int L, hipStream
 // a_ready: ws.a already holds this sub-block's LayerNorm + modulate (written by the previous sub-block's linear2); fuse_next: let this
 // sub-block's linear2 write the next one's when the launch allows it (*a_written reports whether it did)
 int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *mods, int mod_stride, int bc, int T, int L,
-              hipStream_t st, bool a_ready = false, bool fuse_next = false, bool *a_written = nullptr, bool stop_before_linear2 = false) {
+              hipStream_t st, bool a_ready = false, bool fuse_next = false, bool *a_written = nullptr, bool stop_before_linear2 = false,
+              bool stats_ready = false, bool *stats_written = nullptr) {
     const lsl_model_desc &d = m->d;
     const lsl_block_weights &bw = m->blocks[bi];
     const int D = d.hidden, n = bc * T * L, layer = bi / 2, temporal = bi & 1;
     const float *mbase = mods + (size_t)layer * 6 * D + (temporal ? 3 * D : 0);  // shift, scale, gate
-    if (!a_ready) {
+    // handles with lsl_model_set_ln_fuse: linear1 normalises the fp32 residual stream on load (no LayerNorm launch, ws.a unused); never for
+    // the debug taps (which hand out `a`) and only on the workspace's own padded stream
+    const bool tail_m = m->tail && ws.wtail && !stop_before_linear2;
+    // (every condition depends on the model and on T, L only - never on the batch: a trajectory's bits must not)
+    const bool lnf_shape = m->ln_fuse && !tail_m && ws.lnstat && ws.w2p && h == ws.h &&  // (k_tail reads `a` itself; the statistics come from k_linear2_ws)
+                           linear1_lnf_ok(d.head_dim_pad, D, m->F1, m->HHD, n, T * L, mod_stride);
+    const bool lnf = lnf_shape && stats_ready && !a_ready && !stop_before_linear2;  // ws.lnstat holds the statistics of h (the previous linear2's)
+    if (stats_written) *stats_written = false;
+    if (!a_ready && !lnf) {
         m->prof.begin(3, st);
         DISPATCH_D(D, launch_ln_mod_t, ws.a, h, mbase, mbase + D, mod_stride, n, T * L, st);
         m->prof.end(3, st);
@@ -110,7 +119,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     auto magic_of = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };
     if ((unsigned long long)n * (unsigned)std::max(pdiv, pmod) >= (1ull << 32)) return fail(-3, "pass too large for the position arithmetic");
     // tail models (and never the debug taps, which hand out the GELU'd mlp half of z): linear1 computes q | k | v only
-    const bool tail = m->tail && ws.wtail && !stop_before_linear2;
+    const bool tail = tail_m;
     const int F1 = tail ? 3 * m->HHD : m->F1;
     const bool lin1_ts = linear1_ts_ok(d.head_dim_pad, D, F1, m->HHD, n);
     const int npad = (n + 255) & ~255;
@@ -119,11 +128,17 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
     // stream requests): a pass set larger than that through lsl_model_set_chunk / LSL_CHUNK_TRAJ is refused, never wrapped
     if (planes && (unsigned long long)npad * 3ull * (unsigned)m->HHD * 2ull >= (1ull << 32)) return fail(-3, "pass too large for the q/k/v plane offsets (%d tokens: at most %llu with this model)", n, (unsigned long long)((1ull << 32) / (6ull * (unsigned)m->HHD)) - 256);
     if (lin1_ts) {
-        const Lin1Args la{(const u16 *)bw.w1, ws.a, bw.b1, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
+        const Lin1Args la{(const u16 *)bw.w1, lnf ? (const u16 *)h : ws.a, bw.b1, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                           ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, F1, n, m->HHD, d.mlp_dim,
-                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, 0, planes ? 1 : 0, npad};
-        launch_linear1_ts(d.head_dim_pad, D, la, st);
-        m->prof.label(0, "k_linear1_ts<%d, %d, %d>%s", d.head_dim_pad, D, linear1_ts_waves(D, n), tail ? " (q | k | v)" : "");
+                          pdiv, pmod, magic_of(pdiv), magic_of(pmod), 1.0f / d.head_dim, premul, 1, 0, planes ? 1 : 0, npad,
+                          ws.lnstat, mbase, mbase + D, mod_stride, T * L, magic_of(T * L)};
+        if (lnf) {
+            launch_linear1_lnf(d.head_dim_pad, D, la, st);
+            m->prof.label(0, "k_linear1_ts<%d, %d, 8, true>%s", d.head_dim_pad, D, tail ? " (LayerNorm | q | k | v)" : " (LayerNorm fused)");
+        } else {
+            launch_linear1_ts(d.head_dim_pad, D, la, st);
+            m->prof.label(0, "k_linear1_ts<%d, %d, %d>%s", d.head_dim_pad, D, linear1_ts_waves(D, n), tail ? " (q | k | v)" : "");
+        }
     } else if (d.head_dim_pad == 32) {
         EpiLinear1<32> e{bw.b1, bw.qs, bw.ks, temporal ? ws.rope_t : ws.rope_l, ws.rope_qk + (size_t)(2 * bi) * ws.rope_qk_stride,
                          ws.rope_qk + (size_t)(2 * bi + 1) * ws.rope_qk_stride, ws.qkv, ws.z, m->HHD, d.mlp_dim,
@@ -187,13 +202,25 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
         LSL_CHECK_LAUNCH("block (tail)");
         return 0;
     }
-    const bool fuse = fuse_next && bi + 1 < 2 * d.depth && linear2_can_fuse_ln(D, n, m->K2);
+    const bool fuse = fuse_next && !m->ln_fuse && bi + 1 < 2 * d.depth && linear2_can_fuse_ln(D, n, m->K2);  // (ln_fuse handles: linear1 normalises)
     const float *nbase = mods + (size_t)((bi + 1) / 2) * 6 * D + (((bi + 1) & 1) ? 3 * D : 0);  // next sub-block: shift, scale
     bool on_ws = false;
     if (ws.w2p && !fuse && (unsigned long long)n * (unsigned)(4 * D) < (1ull << 32)) {  // (32-bit byte offsets into h)
-        const Lin2Args l2{ws.w2p + (size_t)bi * D * m->K2, ws.z, bw.b2, mbase + 2 * D, h, D, n, mod_stride, T * L, magic_of(T * L), 0, 0, 0};
+        // ln_fuse handles: the rows' statistics for the NEXT sub-block's LayerNorm (inside its linear1) leave with the update
+        const bool stats = lnf_shape && bi + 1 < 2 * d.depth && !stop_before_linear2;
+        const Lin2Args l2{ws.w2p + (size_t)bi * D * m->K2, ws.z, bw.b2, mbase + 2 * D, h, D, n, mod_stride, T * L, magic_of(T * L), 0, 0, 0,
+                          stats ? ws.lnparts : nullptr, npad};
         on_ws = launch_linear2_ws(m->K2, l2, mod_stride == 0, st);
-        if (on_ws) m->prof.label(1, "k_linear2_ws<%d>", m->K2);
+        if (on_ws) m->prof.label(1, stats ? "k_linear2_ws<%d> (+ row statistics)" : "k_linear2_ws<%d>", m->K2);
+        if (on_ws && stats) {
+            hipLaunchKernelGGL(k_ln_finalize, dim3((n + 255) / 256), dim3(256), 0, st, ws.lnstat, ws.lnparts, D / 32, npad, n);
+            if (stats_written) *stats_written = true;
+        }
+        // (which LayerNorm form the next sub-block runs must not depend on the launch: a pass the weight-stationary kernel cannot take - more
+        // trajectories per token range than its gate table holds - is refused on ln_fuse handles, never served by the other form)
+        if (stats && !on_ws) return fail(-3, "ln_fuse: a pass of %d tokens has too many trajectories per token range for k_linear2_ws; use smaller passes (lsl_model_set_chunk)", n);
+    } else if (lnf_shape && bi + 1 < 2 * d.depth && !stop_before_linear2 && !fuse) {
+        return fail(-3, "ln_fuse: pass too large for the residual-stream offsets (%d tokens)", n);
     }
     if (!on_ws) {
         EpiLinear2 e2{bw.b2, mbase + 2 * D, h, D, mod_stride, T * L, 0, magic_of(T * L), fuse ? ws.a : nullptr, nbase, nbase + D};
@@ -229,11 +256,13 @@ int run_eval(lsl_model *m, const Workspace &ws, float *x, float *out, const floa
     m->prof.end(5, st);
     LSL_CHECK_LAUNCH("embed");
     bool a_ready = false;  // the first sub-block of an evaluation runs the standalone LayerNorm; later ones get `a` from the previous linear2
+    bool stats_ready = false;  // ... or (ln_fuse handles) the rows' statistics, and normalise inside their linear1
     for (int bi = 0; bi < 2 * d.depth; ++bi) {
-        bool wrote = false;
-        rc = run_block(m, ws, bi, ws.h, mods, mod_stride, bc, T, L, st, a_ready, true, &wrote);
+        bool wrote = false, wrote_stats = false;
+        rc = run_block(m, ws, bi, ws.h, mods, mod_stride, bc, T, L, st, a_ready, true, &wrote, false, stats_ready, &wrote_stats);
         if (rc) return rc;
         a_ready = wrote;
+        stats_ready = wrote_stats;
     }
     const float *fm = mods + (size_t)d.depth * 6 * D;  // adaLN: shift, scale
     m->prof.begin(4, st);

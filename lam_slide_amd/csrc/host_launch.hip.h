@@ -177,10 +177,10 @@ bool gemm_rows_walk(int F, int N) {
 
 // linear1 on the token-stationary kernel (k_lin1.hip.h): hidden sizes 128 / 256 / 384 / 512, sections (q | k | v | mlp) on multiples of 64
 // features.  Same bits as the tile kernels below (tools/lin1_harness.hip), so the choice between them may depend on the launch size.
-template <int HDP, int K, int NW = 8>
+template <int HDP, int K, int NW = 8, bool LNF = false>
 void launch_linear1_ts_t(const Lin1Args &a, hipStream_t st) {
     using C = Lin1Cfg<HDP, K, NW>;
-    auto kern = k_linear1_ts<HDP, K, NW>;
+    auto kern = k_linear1_ts<HDP, K, NW, LNF>;
     LSL_ALLOW_LDS(kern, (size_t)163840);
     const int ntile = (a.N + C::TT - 1) / C::TT, nb = a.F / 32;
     const long units = (long)ntile * nb;
@@ -191,7 +191,7 @@ void launch_linear1_ts_t(const Lin1Args &a, hipStream_t st) {
     const int wpt = std::min(device_cus() / ntile, nb / 2);
     b.wpt = align && wpt >= 2 ? wpt : 0;
     if (b.wpt) grid = b.wpt * ntile;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), C::lds_bytes(a.F), st, b);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LNF ? C::lds_bytes_lnf(a.F) : C::lds_bytes(a.F), st, b);
 }
 // K = 512, few tokens (md17_bench B = 1: 7 680): 4-wave workgroups on 128-token tiles - twice the tiles, half the activation prologue per
 // workgroup, one wave per SIMD (512 registers: no scratch).  Same bits (tools/lin1_harness.hip -DLIN1_NW=4); 3 840 tokens 24.0 -> 19.9 us,
@@ -210,6 +210,31 @@ bool linear1_ts_ok(int hdp, int D, int F1, int HHD, int N) {
     static const int on = tune_int("LSL_LIN1_TS", 1);
     if (!on || (hdp != 16 && hdp != 32) || (D != 128 && D != 256 && D != 384 && D != 512) || F1 % 64 != 0 || HHD % 64 != 0 || N < 1) return false;
     return (size_t)(D <= 256 ? 4 : 3) * 32 * (2 * D + 16) + 8 * 4096 + (size_t)F1 * 4 <= (size_t)163840;  // weight ring (Lin1Cfg::NS slots) + staging + bias vector (Lin1Cfg::lds_bytes)
+}
+// LayerNorm + modulate inside linear1's activation load (k_lin1.hip.h, LNF instances): no LayerNorm launch, no bf16 `a` buffer - the kernel reads
+// the fp32 residual stream.  Per HANDLE (lsl_model_set_ln_fuse; LSL_LN_FUSE=1 makes it the default of new handles, 0 disables it), never per
+// batch: its rounding differs from the standalone kernel's.  Shapes: the token-stationary kernel's, with the (1 + scale | shift) rows of every
+// trajectory a 256-token tile can touch in LDS - one shared row, or tokens per trajectory >= 128 (hidden <= 256) / >= 256 (wider).
+int ln_fuse_env() {
+    static const int v = env_int("LSL_LN_FUSE", -1);
+    return v;
+}
+bool linear1_lnf_ok(int hdp, int D, int F1, int HHD, int N, int tpt, int mod_stride) {
+    if (ln_fuse_env() == 0 || !linear1_ts_ok(hdp, D, F1, HHD, N) || D % 128 != 0) return false;
+    if (mod_stride != 0 && tpt < (D <= 256 ? 128 : 256)) return false;
+    return (size_t)(D <= 256 ? 4 : 3) * 32 * (2 * D + 16) + 8 * 4096 + (size_t)F1 * 4 + (size_t)(D <= 256 ? 3 : 2) * 2 * D * 4 <= (size_t)163840;
+}
+void launch_linear1_lnf(int hdp, int D, const Lin1Args &a, hipStream_t st) {
+    switch ((hdp == 32 ? 0 : 4) + D / 128 - 1) {
+        case 0: return launch_linear1_ts_t<32, 128, 8, true>(a, st);
+        case 1: return launch_linear1_ts_t<32, 256, 8, true>(a, st);
+        case 2: return launch_linear1_ts_t<32, 384, 8, true>(a, st);
+        case 3: return launch_linear1_ts_t<32, 512, 8, true>(a, st);
+        case 4: return launch_linear1_ts_t<16, 128, 8, true>(a, st);
+        case 5: return launch_linear1_ts_t<16, 256, 8, true>(a, st);
+        case 6: return launch_linear1_ts_t<16, 384, 8, true>(a, st);
+        default: return launch_linear1_ts_t<16, 512, 8, true>(a, st);
+    }
 }
 void launch_linear1_ts(int hdp, int D, const Lin1Args &a, hipStream_t st) {
     switch ((hdp == 32 ? 0 : 4) + D / 128 - 1) {
@@ -231,10 +256,10 @@ bool linear2_ws_shape_ok(int D, int K2) {
     static const int on = env_int("LSL_LIN2_WS", 1);
     return on && D % 128 == 0 && D <= 512 && (K2 == 1536 || K2 == 1280 || K2 == 768 || K2 == 384);
 }
-template <int K, int NCH, int NS>
+template <int K, int NCH, int NS, bool LNS = false>
 bool launch_linear2_ws_t(Lin2Args a, int shared, hipStream_t st) {
     using C = Lin2Cfg<K, NCH, NS, true>;
-    auto kern = k_linear2_ws<K, NCH, NS, true>;
+    auto kern = k_linear2_ws<K, NCH, NS, true, LNS>;
     // grid = 8 x slices x rpx workgroups, at most one per CU; fewer token ranges than 32-token blocks
     const int slices = a.F / 128, cus = device_cus(), NBLK = (a.N + 31) / 32;
     int rpx = std::max(1, cus / (8 * slices));
@@ -250,6 +275,15 @@ bool launch_linear2_ws_t(Lin2Args a, int shared, hipStream_t st) {
     return true;
 }
 bool launch_linear2_ws(int K2, const Lin2Args &a, int shared, hipStream_t st) {
+    if (a.stats) {  // LNS instances: per-wave row statistics of the updated rows beside h (the next sub-block's LayerNorm runs inside linear1)
+        switch (K2) {
+            case 1536: return launch_linear2_ws_t<1536, 3, 3, true>(a, shared, st);
+            case 1280: return launch_linear2_ws_t<1280, 4, 4, true>(a, shared, st);
+            case 768: return launch_linear2_ws_t<768, 3, 3, true>(a, shared, st);
+            case 384: return launch_linear2_ws_t<384, 3, 3, true>(a, shared, st);
+            default: return false;
+        }
+    }
     switch (K2) {
         case 1536: return launch_linear2_ws_t<1536, 3, 3>(a, shared, st);
         case 1280: return launch_linear2_ws_t<1280, 4, 4>(a, shared, st);  // (4 chunks of 160 columns: 40 of 64 lanes per LDS-DMA instruction instead of 32; round 5: 0.168-0.171 -> 0.165 ms at 163 840 tokens, 18.6 -> 17.1 us at 10 240)

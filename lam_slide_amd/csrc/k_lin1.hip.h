@@ -48,6 +48,12 @@ struct Lin1Args {
     int planes;                     // 1 = q / k / v leave as head-major planes qkv[section][head][npad tokens][HDP] (a (sequence, head)'s rows are
                                     // then contiguous: k_attention_stream's spatial units), 0 = token-major rows qkv[token][3 HHD]
     int npad;                       // tokens rounded up to 256 (the plane pitch)
+    // LNF instances (k_linear1_ts<.., true>): X is the fp32 residual stream h [N rounded up to 256][K]; LayerNorm (eps 1e-6) + modulate of this
+    // sub-block (latent_si_v31.py:50-51,57-58) are applied while the rows become MFMA fragments: (x rstd - mean rstd)(1 + scale_k) + shift_k
+    const float2 *ln_stat;             // [N rounded up to 256] (rstd, -mean rstd) per token (k_linear2_ws<LNS> + k_ln_finalize)
+    const float *ln_shift, *ln_scale;  // modulation rows, row stride ln_mod_stride (0: one row shared by every trajectory)
+    int ln_mod_stride, ln_tpt;         // tokens per trajectory
+    unsigned ln_tpt_magic;             // floor(2^32 / tpt) + 1 (0 when tpt == 1)
 };
 
 // K <= 256 (a block is 16 or 8 MFMAs per wave against the same per-step head): 4 ring slots and ONE wait + barrier per PAIR of blocks - both
@@ -81,6 +87,9 @@ struct Lin1Cfg {
     static constexpr int LPR = ROWB / 16;               // active lanes of a DMA instruction: 64 / 48 / 32 / 16
     static constexpr int PPW = 32 / NW;                 // DMA instructions (rows) per wave per block
     static constexpr size_t lds_bytes(int F) { return (size_t)RING + STAGE + (size_t)F * 4; }
+    // LNF: (1 + scale | shift) rows of the trajectories a token tile can touch: 3 (tokens per trajectory >= TT / 2) up to K = 256, 2 (>= TT) above
+    static constexpr int LN_SLOTS = K <= 256 ? 3 : 2;
+    static constexpr size_t lds_bytes_lnf(int F) { return lds_bytes(F) + (size_t)LN_SLOTS * 2 * K * 4; }
 };
 
 enum { LIN1_QK = 0, LIN1_V = 1, LIN1_MLP = 2 };
@@ -105,7 +114,7 @@ __device__ __forceinline__ float lin1_gelu(float x) {
     return fmaf(-ax, h, relu);
 }
 
-template <int HDP, int K, int NW = 8>
+template <int HDP, int K, int NW = 8, bool LNF = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_linear1_ts(Lin1Args g) {
     using C = Lin1Cfg<HDP, K, NW>;
     constexpr int KS = C::KS, BLK = C::BLK, PPW = C::PPW, ROWB = C::ROWB;
@@ -491,6 +500,66 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_linear1_ts(Lin1Args g) {
         }
     };
 
+    // ---- LNF: the wave's 32 rows of the fp32 residual stream -> LayerNorm + modulate -> bf16 B fragments, in one pass: K / 64 passes of one
+    // bf16 line (64 columns = 4 k-steps), 8 line-shaped loads (8 rows x 128 B each) and 32 registers of rows at a time; the rows' statistics
+    // come from the producer of h (Lin1Args::ln_stat), the modulation rows of the tile's trajectories from an LDS table.  The same arithmetic
+    // per element as k_ln_modulate (one rounding to bf16); the statistics are combined in another order, so the operand can differ from the
+    // default path's by an ulp of bf16 here and there: the form is a property of the model handle, never of the launch.
+    float *const ln_tab = bias_lds + ((g.F + 3) & ~3);  // [LN_SLOTS][2][K]: 1 + scale, shift
+    auto traj_of = [&](unsigned n) __attribute__((always_inline)) { return g.ln_tpt_magic ? __umulhi(n, g.ln_tpt_magic) : n; };
+    auto load_x_lnf = [&](int tile_, int nw) __attribute__((always_inline)) {
+        typedef __attribute__((ext_vector_type(4))) float f4;
+        const float *xf = reinterpret_cast<const float *>(g.X);
+        // the modulation rows of the tile's trajectories (uniform: first trajectory of the tile, slots clamped to the pass's last trajectory)
+        const unsigned t_first = g.ln_mod_stride ? traj_of((unsigned)(tile_ * C::TT)) : 0u;
+        const unsigned t_last = g.ln_mod_stride ? traj_of((unsigned)(g.N - 1)) : 0u;
+        for (int i = tid * 4; i < C::LN_SLOTS * K; i += NW * 64 * 4) {
+            const int slot = i / K, col = i - slot * K;
+            const size_t mo = (size_t)min(t_first + (unsigned)slot, t_last) * g.ln_mod_stride + col;
+            const f4 sc = *reinterpret_cast<const f4 *>(g.ln_scale + mo), sh = *reinterpret_cast<const f4 *>(g.ln_shift + mo);
+            *reinterpret_cast<f4 *>(ln_tab + (size_t)slot * 2 * K + col) = f4{1.0f + sc[0], 1.0f + sc[1], 1.0f + sc[2], 1.0f + sc[3]};
+            *reinterpret_cast<f4 *>(ln_tab + (size_t)slot * 2 * K + K + col) = sh;
+        }
+        const unsigned rowi = lane >> 3, chunk = lane & 7;
+        const unsigned sbase = (unsigned)(size_t)(LDS_PTR(char))(stage);
+        const unsigned xr0 = sbase + r * 128;
+        const float *xr = xf + (size_t)(nw + rowi) * K + 4 * chunk;
+        float2 st[4];        // (rstd, -mean rstd) of rows rowi + 8 q
+        const float *tb[4];  // their trajectory's table row, at the lane's first column
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned nn = (unsigned)min(nw + (int)rowi + 8 * q, g.N - 1);
+            st[q] = g.ln_stat[nn];
+            const unsigned slot = g.ln_mod_stride ? min(traj_of(nn) - t_first, (unsigned)(C::LN_SLOTS - 1)) : 0u;
+            tb[q] = ln_tab + (size_t)slot * 2 * K + 4 * chunk;
+        }
+        __syncthreads();  // the table is complete (every wave left the previous segment's long ago: a segment has at least one block barrier)
+#pragma unroll
+        for (int p = 0; p < K / 64; ++p) {
+            f4 v[2][4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[e][q] = *reinterpret_cast<const f4 *>(xr + (size_t)(8 * q) * K + 64 * p + 32 * e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned row = rowi + 8 * q, sw = (row >> 1) & 7;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const f4 sc = *reinterpret_cast<const f4 *>(tb[q] + 64 * p + 32 * e), sh = *reinterpret_cast<const f4 *>(tb[q] + K + 64 * p + 32 * e);
+                    f4 x = v[e][q];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = fmaf(x[c], st[q].x, st[q].y) * sc[c] + sh[c];
+                    const u32x2 pk = {pack2(x[0], x[1]), pack2(x[2], x[3])};
+                    *reinterpret_cast<LDS_PTR(u32x2)>(sbase + row * 128 + ((((4 * e + (chunk >> 1)) ^ sw) & 7) << 4) + 8 * (chunk & 1)) = pk;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                xreg[4 * p + m] = as_bf16x8(*reinterpret_cast<const LDS_PTR(u32x4)>(xr0 + ((((2 * m + hf) ^ (r >> 1)) & 7) << 4)));
+            __builtin_amdgcn_sched_barrier(0);  // (one pass's rows at a time)
+        }
+    };
     const int qb = g.HHD >> 5;  // blocks per q / k / v section
     // (tile, first block, blocks left in the range): no division inside the loop - a later segment always starts a tile at block 0
     int tile = (int)(i0 / NB), b0 = (int)(i0 - (long)tile * NB), left = (int)(i1 - i0);
@@ -503,8 +572,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_linear1_ts(Lin1Args g) {
         row_q = reinterpret_cast<const char *>(g.qkv) + (size_t)n_wave * stride_q;
         row_z = reinterpret_cast<const char *>(g.z) + (size_t)n_wave * stride_z - 4 * (size_t)g.HHD;  // (z column of feature f: f - 2 HHD)
         // the wave's tokens: B fragments of all k-steps (X is padded to whole tiles)
-        if (first_seg) load_x(n_wave);  // (later segments: requested at the end of the previous one)
-        finish_x();
+        if constexpr (LNF) load_x_lnf(tile, n_wave);  // (a prefetch of the next tile's rows at the end of a segment - 32 to 128 registers - was tried:
+        else {                                          // hipcc spills it, 256-640 B of scratch at K = 512)
+            if (first_seg) load_x(n_wave);  // (later segments: requested at the end of the previous one)
+            finish_x();
+        }
         const unsigned nn = (unsigned)min(n_wave + r, g.N - 1);
         const unsigned n1 = g.div_magic ? __umulhi(nn, g.div_magic) : nn;
         const unsigned pos = g.mod_magic ? n1 - __umulhi(n1, g.mod_magic) * (unsigned)g.pos_mod : 0u;
@@ -571,7 +643,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_linear1_ts(Lin1Args g) {
         if (left_next > 0) {  // (uniform) the next segment: tile + 1 from block 0, i.e. the q section
             asm volatile("" ::: "memory");
             const int nw = (tile + 1) * C::TT + wave * 32;
-            load_x(nw);
+            if constexpr (!LNF) load_x(nw);
             if (b1 - 1 >= 2 * qb) {  // the drain below is not a q / k block: co is free for the next segment's q table
                 const unsigned nn2 = (unsigned)min(nw + r, g.N - 1);
                 const unsigned m1 = g.div_magic ? __umulhi(nn2, g.div_magic) : nn2;

@@ -45,6 +45,11 @@ struct Lin2Args {
     unsigned tpt_magic;   // floor(2^32 / tpt) + 1 (0 when tpt == 1)
     int slices, rpx;      // feature slices of 128 (F / 128) and token ranges per XCD: grid = 8 * slices * rpx
     int gate_rows;        // rows of the LDS gate table (>= the trajectories one token range spans; host-checked)
+    // LNS instances (round 6: the next sub-block's LayerNorm inside linear1, k_lin1.hip.h LNF): beside h, every hi wave leaves
+    //   stats [F / 32][npad] float2 = (mean, sum of squared deviations) of each UPDATED token row over the wave's 32 features,
+    // which k_ln_finalize combines into the row's (rstd, -mean rstd).  h itself is bit-identical to the plain instance's.
+    float2 *stats;
+    int npad;
 };
 
 #ifndef LIN2_PD
@@ -101,7 +106,7 @@ __global__ void __launch_bounds__(256) k_lin2_pack(u16 *out, const u16 *W, int F
     }
 }
 
-template <int K, int NCH, int NS, bool HB2>
+template <int K, int NCH, int NS, bool HB2, bool LNS = false>
 __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
     using C = Lin2Cfg<K, NCH, NS, HB2>;
     constexpr int KSH = C::KSH, KC = C::KC, MPC = C::MPC, PITCH = C::PITCH, CHUNK = C::CHUNK, PD = LIN2_PD;
@@ -295,7 +300,8 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
     };
     auto epi_math = [&](int b) __attribute__((always_inline)) {  // block b: register group q = features 8 q + 4 hf .. + 3 of token r
         const int l = opaque_lane(), rr = l & 31, hh = l >> 5;
-        const unsigned n = (unsigned)min((blk0 + b) * 32 + rr, g.N - 1);
+        const int n_row = (blk0 + b) * 32 + rr;
+        const unsigned n = (unsigned)min(n_row, g.N - 1);
         const unsigned traj = g.mod_stride ? (g.tpt_magic ? __umulhi(n, g.tpt_magic) : n) - traj_lo : 0u;
         const float *bp = bias_lds + 32 * p + 4 * hh, *gp = gate_lds + traj * 128 + 32 * p + 4 * hh;
         char *hrow = hbuf + hb_off(b) + rr * 128;
@@ -310,6 +316,41 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
             hv.z = fmaf(gt.z, acc[4 * q + 2] + bs.z, hv.z);
             hv.w = fmaf(gt.w, acc[4 * q + 3] + bs.w, hv.w);
             *hp = hv;
+        }
+    };
+    // (LNS) statistics of block b's UPDATED rows, read back from the LDS image epi_math has just rewritten.  Measured in both places: behind
+    // epi_math (here) linear2 + 14 ms per cfg-2 step, inside the MFMA chain of the block-step + 19 ms (profiles/r06_experiments.txt section 12)
+    auto epi_stats = [&](int b) __attribute__((always_inline)) {
+        const int l = opaque_lane(), rr = l & 31, hh = l >> 5;
+        const int n_row = (blk0 + b) * 32 + rr;
+        const char *hrow = hbuf + hb_off(b) + rr * 128;
+        if constexpr (LNS) {
+            // Statistics of the updated row over this wave's 32 features, as a pass of its own over the LDS image (the accumulators are dead here;
+            // running sums inside the loop above spill): the lane's 16 values, two-pass, then the row's 32 (the other half sits on lane ^ 32) by
+            // the pairwise update of Chan et al. - both lanes compute the same symmetric expression.  One 8-byte store per row and wave.
+            float4 w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const float4 *>(hrow + 16 * ((2 * q + hh) ^ (rr & 7)));
+            float s1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s1 += (w[q].x + w[q].y) + (w[q].z + w[q].w);
+            const float m16 = s1 * (1.0f / 16.0f);
+            float q16 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dx = w[q].x - m16, dy = w[q].y - m16, dz = w[q].z - m16, dw = w[q].w - m16;
+                q16 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            // (the two halves' values through v_permlane32_swap: vector moves, not two round trips through the LDS queue)
+            const auto pm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m16), __float_as_uint(m16), false, false);
+            const auto pq = __builtin_amdgcn_permlane32_swap(__float_as_uint(q16), __float_as_uint(q16), false, false);
+            const float m_lo = __uint_as_float((unsigned)pm[0]), m_hi = __uint_as_float((unsigned)pm[1]), dm = m_lo - m_hi;
+            const u32x2 st = {__float_as_uint(0.5f * (m_lo + m_hi)),
+                              __float_as_uint((__uint_as_float((unsigned)pq[0]) + __uint_as_float((unsigned)pq[1])) + 8.0f * dm * dm)};
+            if (hh == 0 && n_row < g.N) {
+                const unsigned voff = (unsigned)(((f0 >> 5) * g.npad + n_row) * 8);
+                asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(st), "s"(g.stats) : "memory");
+            }
         }
     };
     auto epi_store = [&](int b, int i, bool ragged) __attribute__((always_inline)) {  // rows 8 i .. 8 i + 7 of block b, whole 128-byte segments
@@ -347,10 +388,11 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
                 // chain from the lo wave
                 if (B >= 1) {
                     if (!HB2) wait_vmcnt<0>();
-                    else if (B >= 2) wait_vmcnt<8>();
+                    else if (B >= 2) wait_vmcnt<8 + (LNS ? 1 : 0)>();  // (LNS: + the statistics store of the block before)
                     else wait_vmcnt<4>();
                     asm volatile("" ::: "memory");
                     epi_math(B - 1);
+                    epi_stats(B - 1);
                 }
                 const int l = opaque_lane();
 #pragma unroll
@@ -379,6 +421,7 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
         const int b = nblk - 1;
         const bool ragged = (blk0 + b) * 32 + 32 > g.N;
         epi_math(b);
+        epi_stats(b);
 #pragma unroll
         for (int i = 0; i < 4; ++i) epi_store(b, i, ragged);
     }

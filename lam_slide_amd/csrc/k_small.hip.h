@@ -551,6 +551,24 @@ __global__ void __launch_bounds__(256) k_ln_modulate_v4(u16 *a, const float *h, 
     }
 }
 
+// Per-token LayerNorm statistics from the per-wave partials k_linear2_ws<LNS> leaves beside the residual stream (round 6): parts = D / 32 pairs
+// (mean, sum of squared deviations) over 32 features each, plane-major [part][npad]; combined in part order by the pairwise update of Chan et
+// al. (a fixed order: a token's statistics do not depend on the launch) into (rstd, -mean rstd), eps 1e-6 like k_ln_modulate.
+__global__ void __launch_bounds__(256) k_ln_finalize(float2 *tok, const float2 *parts_in, int parts, int npad, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float msum = 0.0f, q = 0.0f;
+    for (int p = 0; p < parts; ++p) msum += parts_in[(size_t)p * npad + n].x;
+    const float mean = msum / (float)parts;
+    for (int p = 0; p < parts; ++p) {
+        const float2 st = parts_in[(size_t)p * npad + n];
+        const float d = st.x - mean;
+        q += st.y + 32.0f * d * d;
+    }
+    const float rstd = rsqrtf(q / (float)(32 * parts) + 1e-6f);
+    tok[n] = make_float2(rstd, -mean * rstd);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Runge-Kutta arithmetic of the adaptive ODE sampler (lam_slide_amd/transport.py: dopri5_solve; the reference reaches torchdiffeq's
 // rk_common.py through integrators.py:67-78): stage states, the solution, the dense-output coefficients and the error ratio of a step, fp32.

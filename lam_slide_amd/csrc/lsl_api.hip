@@ -70,6 +70,7 @@ int lsl_model_create(const lsl_model_desc *desc, lsl_model **out) try {
     m->K2 = m->HHD + d.mlp_dim;
     m->MODW = (6 * d.depth + 2) * d.hidden;
     m->tail = tail_env() == 1 && tail_shape_ok(d.hidden, m->HHD, d.mlp_dim);
+    m->ln_fuse = ln_fuse_env() == 1;
     *out = m;
     return 0;
 } catch (const std::bad_alloc &) {
@@ -187,6 +188,18 @@ int lsl_model_set_tail(lsl_model *m, int32_t on) try {
     return fail(-11, "unexpected C++ exception");
 }
 int32_t lsl_model_tail(const lsl_model *m) { return m && m->tail ? 1 : 0; }
+int lsl_model_set_ln_fuse(lsl_model *m, int32_t on) try {
+    if (!m || (on != 0 && on != 1)) return fail(-1, "ln_fuse must be 0 or 1");
+    if (on && ln_fuse_env() == 0) return fail(-21, "LayerNorm fusion is disabled (LSL_LN_FUSE=0)");
+    if (m->ln_fuse != (on == 1)) drop_graphs(m);
+    m->ln_fuse = on == 1;
+    return 0;
+} catch (const std::bad_alloc &) {
+    return fail(-5, "out of host memory");
+} catch (...) {
+    return fail(-11, "unexpected C++ exception");
+}
+int32_t lsl_model_ln_fuse(const lsl_model *m) { return m && m->ln_fuse ? 1 : 0; }
 const char *lsl_profile_kernel_name(const lsl_model *m) { return m ? m->prof.name : ""; }
 
 int32_t lsl_pass_size(const lsl_model *m, int32_t B, int32_t T, int32_t L) {

@@ -128,6 +128,7 @@ class LatentSIV3(nn.Module):
         self._pinned: "OrderedDict[tuple, Tensor]" = OrderedDict()
         self._chunk = 0
         self._tail = None  # None: the library's default (LSL_TAIL); True / False: set_tail
+        self._ln_fuse = None  # likewise (LSL_LN_FUSE / set_ln_fuse)
         self.last_path = None  # "hip" after a forward, for tests that must prove the native path ran
 
     # ---- initialisation recipe of the reference (latent_si_v31.py:123-156) ----------------------------
@@ -180,6 +181,8 @@ class LatentSIV3(nn.Module):
                 lib.lsl_model_set_chunk(self._handle, self._chunk)
             if self._tail is not None:
                 _lib.check(lib.lsl_model_set_tail(self._handle, int(self._tail)))
+            if self._ln_fuse is not None:
+                _lib.check(lib.lsl_model_set_ln_fuse(self._handle, int(self._ln_fuse)))
             if self.attention_mode != "scaled_dot_product":
                 _lib.check(lib.lsl_model_set_attention_mode(self._handle, 1))
         return self._packed
@@ -192,6 +195,19 @@ class LatentSIV3(nn.Module):
         self._tail = bool(on)
         if self._handle:
             _lib.check(_lib.load().lsl_model_set_tail(self._handle, int(self._tail)))
+
+    def set_ln_fuse(self, on: bool):
+        """LayerNorm + modulate inside linear1's activation load (include/lsl_api.h, ``lsl_model_set_ln_fuse``): no LayerNorm launch, linear1
+        reads the fp32 residual stream.  Faster from about 10^5 tokens per pass, slower at small launches; one more bf16 rounding than the
+        standalone kernel.  A property of the model object, never of the batch."""
+        self._ln_fuse = bool(on)
+        if self._handle:
+            _lib.check(_lib.load().lsl_model_set_ln_fuse(self._handle, int(self._ln_fuse)))
+
+    @property
+    def ln_fuse(self) -> bool:
+        """Whether the native handle fuses the LayerNorm into linear1 (False before the weights are packed)."""
+        return bool(self._handle) and bool(_lib.load().lsl_model_ln_fuse(self._handle))
 
     @property
     def tail(self) -> bool:

@@ -39,7 +39,7 @@ def build_net(sh, params, dev):
 def test_library_loaded_and_fails_loudly_on_cpu(dev):
     from lam_slide_amd import LatentSIV3, _lib
     lib = _lib.load()
-    assert lib.lsl_version() == _lib.ABI_VERSION == 5
+    assert lib.lsl_version() == _lib.ABI_VERSION == 6
     net = LatentSIV3(depth=1, in_dim=8, hidden_size=64, num_heads=4, reset_parameters=False)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 2, 3, 8), torch.zeros(1), torch.zeros(1, 2, 3, 8), torch.zeros(1, 2, 3, dtype=torch.long))

@@ -105,6 +105,8 @@ def main():
             kernels[name]["note"] = f"trace calls {st['calls']} != {n_f} launches x {a.calls} sampling calls"
     out = {"note": __doc__.split("\n\n")[2].replace("\n", " "), "source": os.path.relpath(a.summary), "workload": a.workload, "batch": a.batch,
            "tokens_per_step": a.batch * a.tokens_per_traj, "kernels": kernels}
+    if bl and bl["config"].get("ln_fuse"):
+        out["ln_fuse"] = True  # the handle fused the LayerNorm into linear1 (bench.py config.ln_fuse): class "linear1" reads the fp32 residual stream
     if bl and bl["config"].get("tail"):
         out["tail"] = True  # the handle ran the tail decomposition (bench.py config.tail): class "linear2" is k_tail, "linear1" computes q | k | v only
     if a.updates:
