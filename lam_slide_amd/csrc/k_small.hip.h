@@ -557,13 +557,17 @@ __global__ void __launch_bounds__(256) k_ln_modulate_v4(u16 *a, const float *h, 
 __global__ void __launch_bounds__(256) k_ln_finalize(float2 *tok, const float2 *parts_in, int parts, int npad, int N) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
+    float2 st[16];  // (parts <= 16: hidden <= 512; one pass over the partials, all requests in flight together)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) st[p] = p < parts ? parts_in[(size_t)p * npad + n] : make_float2(0.0f, 0.0f);
     float msum = 0.0f, q = 0.0f;
-    for (int p = 0; p < parts; ++p) msum += parts_in[(size_t)p * npad + n].x;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) msum += st[p].x;
     const float mean = msum / (float)parts;
-    for (int p = 0; p < parts; ++p) {
-        const float2 st = parts_in[(size_t)p * npad + n];
-        const float d = st.x - mean;
-        q += st.y + 32.0f * d * d;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const float d = st[p].x - mean;
+        if (p < parts) q += st[p].y + 32.0f * d * d;
     }
     const float rstd = rsqrtf(q / (float)(32 * parts) + 1e-6f);
     tok[n] = make_float2(rstd, -mean * rstd);
