@@ -298,6 +298,33 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(g.h), "s"(dst) : "memory");
         }
     };
+    // (LNS) statistics of block b's UPDATED row over this wave's 32 features, from the values epi_math has just computed (in registers: read back
+    // from the LDS image they cost a write -> read turn-around on the hi waves' critical path): the lane's 16 values, two-pass, then the row's 32
+    // (the other half sits on lane ^ 32) by the pairwise update of Chan et al. - both lanes compute the same symmetric expression, the exchange
+    // is two v_permlane32_swap.  One 8-byte store per row and wave.
+    auto epi_stats_regs = [&](int b, const float4 (&w)[4]) __attribute__((always_inline)) {
+        const int l = opaque_lane(), rr = l & 31, hh = l >> 5;
+        const int n_row = (blk0 + b) * 32 + rr;
+        float s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s1 += (w[q].x + w[q].y) + (w[q].z + w[q].w);
+        const float m16 = s1 * (1.0f / 16.0f);
+        float q16 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dx = w[q].x - m16, dy = w[q].y - m16, dz = w[q].z - m16, dw = w[q].w - m16;
+            q16 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        const auto pm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m16), __float_as_uint(m16), false, false);
+        const auto pq = __builtin_amdgcn_permlane32_swap(__float_as_uint(q16), __float_as_uint(q16), false, false);
+        const float m_lo = __uint_as_float((unsigned)pm[0]), m_hi = __uint_as_float((unsigned)pm[1]), dm = m_lo - m_hi;
+        const u32x2 st = {__float_as_uint(0.5f * (m_lo + m_hi)),
+                          __float_as_uint((__uint_as_float((unsigned)pq[0]) + __uint_as_float((unsigned)pq[1])) + 8.0f * dm * dm)};
+        if (hh == 0 && n_row < g.N) {
+            const unsigned voff = (unsigned)(((f0 >> 5) * g.npad + n_row) * 8);
+            asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(st), "s"(g.stats) : "memory");
+        }
+    };
     auto epi_math = [&](int b) __attribute__((always_inline)) {  // block b: register group q = features 8 q + 4 hf .. + 3 of token r
         const int l = opaque_lane(), rr = l & 31, hh = l >> 5;
         const int n_row = (blk0 + b) * 32 + rr;
@@ -305,6 +332,7 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
         const unsigned traj = g.mod_stride ? (g.tpt_magic ? __umulhi(n, g.tpt_magic) : n) - traj_lo : 0u;
         const float *bp = bias_lds + 32 * p + 4 * hh, *gp = gate_lds + traj * 128 + 32 * p + 4 * hh;
         char *hrow = hbuf + hb_off(b) + rr * 128;
+        float4 w[4];  // (LNS) the updated values, for the row statistics below: they take over the registers of the accumulators they consume
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 bs = *reinterpret_cast<const float4 *>(bp + 8 * q);
@@ -316,42 +344,9 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
             hv.z = fmaf(gt.z, acc[4 * q + 2] + bs.z, hv.z);
             hv.w = fmaf(gt.w, acc[4 * q + 3] + bs.w, hv.w);
             *hp = hv;
+            if constexpr (LNS) w[q] = hv;
         }
-    };
-    // (LNS) statistics of block b's UPDATED rows, read back from the LDS image epi_math has just rewritten.  Measured in both places: behind
-    // epi_math (here) linear2 + 14 ms per cfg-2 step, inside the MFMA chain of the block-step + 19 ms (profiles/r06_experiments.txt section 12)
-    auto epi_stats = [&](int b) __attribute__((always_inline)) {
-        const int l = opaque_lane(), rr = l & 31, hh = l >> 5;
-        const int n_row = (blk0 + b) * 32 + rr;
-        const char *hrow = hbuf + hb_off(b) + rr * 128;
-        if constexpr (LNS) {
-            // Statistics of the updated row over this wave's 32 features, as a pass of its own over the LDS image (the accumulators are dead here;
-            // running sums inside the loop above spill): the lane's 16 values, two-pass, then the row's 32 (the other half sits on lane ^ 32) by
-            // the pairwise update of Chan et al. - both lanes compute the same symmetric expression.  One 8-byte store per row and wave.
-            float4 w[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const float4 *>(hrow + 16 * ((2 * q + hh) ^ (rr & 7)));
-            float s1 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s1 += (w[q].x + w[q].y) + (w[q].z + w[q].w);
-            const float m16 = s1 * (1.0f / 16.0f);
-            float q16 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float dx = w[q].x - m16, dy = w[q].y - m16, dz = w[q].z - m16, dw = w[q].w - m16;
-                q16 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-            }
-            // (the two halves' values through v_permlane32_swap: vector moves, not two round trips through the LDS queue)
-            const auto pm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m16), __float_as_uint(m16), false, false);
-            const auto pq = __builtin_amdgcn_permlane32_swap(__float_as_uint(q16), __float_as_uint(q16), false, false);
-            const float m_lo = __uint_as_float((unsigned)pm[0]), m_hi = __uint_as_float((unsigned)pm[1]), dm = m_lo - m_hi;
-            const u32x2 st = {__float_as_uint(0.5f * (m_lo + m_hi)),
-                              __float_as_uint((__uint_as_float((unsigned)pq[0]) + __uint_as_float((unsigned)pq[1])) + 8.0f * dm * dm)};
-            if (hh == 0 && n_row < g.N) {
-                const unsigned voff = (unsigned)(((f0 >> 5) * g.npad + n_row) * 8);
-                asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(st), "s"(g.stats) : "memory");
-            }
-        }
+        if constexpr (LNS) epi_stats_regs(b, w);
     };
     auto epi_store = [&](int b, int i, bool ragged) __attribute__((always_inline)) {  // rows 8 i .. 8 i + 7 of block b, whole 128-byte segments
         const int l = opaque_lane(), tr = l >> 3, ch = (l & 7) ^ (tr & 7);
@@ -392,7 +387,6 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
                     else wait_vmcnt<4>();
                     asm volatile("" ::: "memory");
                     epi_math(B - 1);
-                    epi_stats(B - 1);
                 }
                 const int l = opaque_lane();
 #pragma unroll
@@ -421,7 +415,6 @@ __global__ void __launch_bounds__(512, 2) k_linear2_ws(Lin2Args g) {
         const int b = nblk - 1;
         const bool ragged = (blk0 + b) * 32 + 32 > g.N;
         epi_math(b);
-        epi_stats(b);
 #pragma unroll
         for (int i = 0; i < 4; ++i) epi_store(b, i, ragged);
     }
