@@ -21,6 +21,10 @@
 //     whole 128-byte row segments;
 //   * work = (token tile, block) pairs in one linear order, cut into equal contiguous ranges: every workgroup does the same number of
 //     blocks whatever the tile count (no fractional last round).
+//   * LNF = true (round 6; lsl_model_set_ln_fuse): X is the fp32 residual stream - the wave's rows arrive as 128-byte lines, are normalised and
+//     modulated (LayerNorm + modulate of the sub-block, statistics from k_linear2_ws<LNS> + k_ln_finalize, modulation rows in an LDS table),
+//     rounded once and turned into the same fragments through the staging image: no LayerNorm launch, no bf16 operand buffer.  Costs the launch
+//     ~ 36 us at 245 760 x 512 (the rows arrive behind the previous segment's store acknowledgements), saves the 130 us LayerNorm launch.
 //   * NW = 4 (round 6): the same kernel on 4-wave workgroups and 128-token tiles - one wave per SIMD (512 registers: no scratch at K = 512), every
 //     wave requests 8 rows of a block.  Same bits.  Slower wherever the launch is large (a lone wave's latencies have no partner to fill them:
 //     709.8 vs 610.9 us at 245 760 x 512), faster where the activation prologue dominates: K = 512 up to ~10 000 tokens (host_launch.hip.h).
