@@ -202,7 +202,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
         LSL_CHECK_LAUNCH("block (tail)");
         return 0;
     }
-    const bool fuse = fuse_next && !m->ln_fuse && bi + 1 < 2 * d.depth && linear2_can_fuse_ln(D, n, m->K2);  // (ln_fuse handles: linear1 normalises)
+    const bool fuse = fuse_next && !lnf_shape && bi + 1 < 2 * d.depth && linear2_can_fuse_ln(D, n, m->K2);  // (where the ln_fuse form applies, linear1 normalises)
     const float *nbase = mods + (size_t)((bi + 1) / 2) * 6 * D + (((bi + 1) & 1) ? 3 * D : 0);  // next sub-block: shift, scale
     bool on_ws = false;
     if (ws.w2p && !fuse && (unsigned long long)n * (unsigned)(4 * D) < (1ull << 32)) {  // (32-bit byte offsets into h)
