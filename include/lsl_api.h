@@ -165,7 +165,8 @@ int32_t lsl_model_tail(const lsl_model *m); /* 1 if the handle runs the tail for
  * bf16 operand `a`, linear1 reads it.  1: no LayerNorm launch - linear1 reads the fp32 residual stream, normalises and modulates its rows while
  * it turns them into MFMA fragments (1.5 KB of HBM traffic per token and sub-block less at hidden 512, measured; faster from about 10^5 tokens per pass,
  * slower at small launches).  Wherever the token-stationary linear1 runs with its modulation rows in LDS (one shared row, or >= 128 / 256 tokens
- * per trajectory at hidden <= 256 / above); elsewhere, and on handles in the tail form, the standalone kernel stays.  One more bf16 rounding of a
+ * per trajectory at hidden <= 256 / above; the first sub-block of an evaluation when the embedding kernel can leave the statistics: hidden 256 / 512,
+ * <= 32 input channels, normalize = false); elsewhere, and on handles in the tail form, the standalone kernel stays.  One more bf16 rounding of a
  * deviation-sized value than the standalone kernel: results differ at the level of the bf16 operand (same error class against the fp32
  * reference), so the choice belongs to the MODEL HANDLE, never to the batch.  Environment LSL_LN_FUSE=1 / 0: default of new handles / disabled. */
 int lsl_model_set_ln_fuse(lsl_model *m, int32_t on);

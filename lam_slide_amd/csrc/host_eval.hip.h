@@ -213,7 +213,7 @@ int run_block(lsl_model *m, const Workspace &ws, int bi, float *h, const float *
         on_ws = launch_linear2_ws(m->K2, l2, mod_stride == 0, st);
         if (on_ws) m->prof.label(1, stats ? "k_linear2_ws<%d> (+ row statistics)" : "k_linear2_ws<%d>", m->K2);
         if (on_ws && stats) {
-            hipLaunchKernelGGL(k_ln_finalize, dim3((n + 255) / 256), dim3(256), 0, st, ws.lnstat, ws.lnparts, D / 32, npad, n);
+            hipLaunchKernelGGL(k_ln_finalize, dim3((n + 255) / 256), dim3(256), 0, st, ws.lnstat, ws.lnparts, D / 32, npad, n, 32.0f);
             if (stats_written) *stats_written = true;
         }
         // (which LayerNorm form the next sub-block runs must not depend on the launch: a pass the weight-stationary kernel cannot take - more
@@ -251,12 +251,18 @@ int run_eval(lsl_model *m, const Workspace &ws, float *x, float *out, const floa
     else rc = run_mods(m, ws, t_dev, t_scalar, have_y ? ws.yemb : nullptr, rows, ws.vec, ws.mods, st);
     if (rc) return rc;
     m->prof.begin(5, st);
-    launch_embed<1>(ws.h, x, m->w.x_in_w, nullptr, nullptr, nullptr, nullptr, ws.cond_emb, n, d.in_dim, D, st);
+    // ln_fuse handles (models without the in-place LayerNorm behind the embedding): the embedding leaves the rows' statistics, so that the
+    // FIRST sub-block's LayerNorm runs inside its linear1 too (the same shape conditions as run_block's, which decide there again)
+    const int npad_e = (n + 255) & ~255;
+    const bool emb_stats = m->ln_fuse && !m->tail && !d.normalize && ws.lnstat && ws.w2p && embed_stats_ok(d.in_dim, D) &&
+                           linear1_lnf_ok(d.head_dim_pad, D, m->F1, m->HHD, n, T * L, mod_stride);
+    launch_embed<1>(ws.h, x, m->w.x_in_w, nullptr, nullptr, nullptr, nullptr, ws.cond_emb, n, d.in_dim, D, st, emb_stats ? ws.lnparts : nullptr, npad_e);
+    if (emb_stats) hipLaunchKernelGGL(k_ln_finalize, dim3((n + 255) / 256), dim3(256), 0, st, ws.lnstat, ws.lnparts, D / 256, npad_e, n, 256.0f);
     if (d.normalize) { DISPATCH_D(D, launch_ln_inplace_t, ws.h, n, 1e-5f, st); }
     m->prof.end(5, st);
     LSL_CHECK_LAUNCH("embed");
     bool a_ready = false;  // the first sub-block of an evaluation runs the standalone LayerNorm; later ones get `a` from the previous linear2
-    bool stats_ready = false;  // ... or (ln_fuse handles) the rows' statistics, and normalise inside their linear1
+    bool stats_ready = emb_stats;  // ... or (ln_fuse handles) the rows' statistics, and normalise inside their linear1
     for (int bi = 0; bi < 2 * d.depth; ++bi) {
         bool wrote = false, wrote_stats = false;
         rc = run_block(m, ws, bi, ws.h, mods, mod_stride, bc, T, L, st, a_ready, true, &wrote, false, stats_ready, &wrote_stats);

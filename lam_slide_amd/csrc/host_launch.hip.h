@@ -82,9 +82,11 @@ void launch_head_t(float *x, float *out, const float *h, const float *shift, con
 
 int device_cus();
 
+// (stats / npad: ln_fuse handles, launch_embed<1> only - the rows' statistics for the first sub-block's fused LayerNorm; embed_stats_ok says where)
+bool embed_stats_ok(int C, int D) { return C <= 32 && D % 256 == 0 && D <= 512; }
 template <int MODE>
 int launch_embed(float *out, const float *in, const float *W, const float *b, const float *b2, const float *me,
-                 const int64_t *mask, const float *base, int n, int C, int D, hipStream_t st) {
+                 const int64_t *mask, const float *base, int n, int C, int D, hipStream_t st, float2 *stats = nullptr, int npad = 0) {
     if (C > 32 && C % 8 == 0 && C <= 128 && D % 32 == 0) {  // wide inputs: fp32 MFMA form (k_embed_mfma)
         const int tpw = 3, ngrp = (D / 32 + tpw - 1) / tpw;
         const long units = (long)((n + 31) / 32) * ngrp;
@@ -107,12 +109,18 @@ int launch_embed(float *out, const float *in, const float *W, const float *b, co
     const dim3 grid(std::min((n + tok - 1) / tok, 2 * device_cus())), blk(256);
     if (C <= 32) {
         const size_t lds = w_lds ? embed_w_lds_bytes<32, 4>(D) : 0;
+        if (stats && MODE == 1 && embed_stats_ok(C, D)) {
+            auto kern = k_embed<32, 1, 4, true>;
+            LSL_ALLOW_LDS(kern, (embed_w_lds_bytes<32, 4>(512)));
+            hipLaunchKernelGGL(kern, grid, blk, lds, st, out, in, W, b, b2, me, mask, base, n, C, D, w_lds ? 1 : 0, tok, stats, npad);
+            return 0;
+        }
         auto kern = k_embed<32, MODE, 4>;
         LSL_ALLOW_LDS(kern, (embed_w_lds_bytes<32, 4>(512)));
-        hipLaunchKernelGGL(kern, grid, blk, lds, st, out, in, W, b, b2, me, mask, base, n, C, D, w_lds ? 1 : 0, tok);
-    } else if (C <= 64) hipLaunchKernelGGL((k_embed<64, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D, 0, tok);
-    else if (C <= 96) hipLaunchKernelGGL((k_embed<96, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D, 0, tok);
-    else hipLaunchKernelGGL((k_embed<128, MODE, 1>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D, 0, tok);
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, out, in, W, b, b2, me, mask, base, n, C, D, w_lds ? 1 : 0, tok, (float2 *)nullptr, 0);
+    } else if (C <= 64) hipLaunchKernelGGL((k_embed<64, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D, 0, tok, (float2 *)nullptr, 0);
+    else if (C <= 96) hipLaunchKernelGGL((k_embed<96, MODE, 2>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D, 0, tok, (float2 *)nullptr, 0);
+    else hipLaunchKernelGGL((k_embed<128, MODE, 1>), grid, blk, 0, st, out, in, W, b, b2, me, mask, base, n, C, D, 0, tok, (float2 *)nullptr, 0);
     return 0;
 }
 

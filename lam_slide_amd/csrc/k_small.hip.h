@@ -258,10 +258,13 @@ __global__ void __launch_bounds__(256) k_dense_mfma(float *out, const float *in,
 constexpr int EMB_TOK = 64;
 template <int CMAX, int ND>
 constexpr size_t embed_w_lds_bytes(int D) { return (size_t)(D / ND) * (ND * CMAX / 4 + 1) * 16; }
-template <int CMAX, int MODE, int ND>  // ND output columns per thread: 4 (C <= 32), 2 (C <= 96), 1
+// STATS (round 6, ln_fuse handles; D a multiple of 64 ND): beside `out`, every wave leaves (mean, sum of squared deviations) of each token row
+// over its 64 ND features in stats[D / (64 ND)][npad] - what k_ln_finalize (group size 64 ND) turns into the first sub-block's LayerNorm
+// statistics; `out` itself is bit-identical to the plain instance's.
+template <int CMAX, int MODE, int ND, bool STATS = false>  // ND output columns per thread: 4 (C <= 32), 2 (C <= 96), 1
 __global__ void __launch_bounds__(256) k_embed(float *out, const float *in, const float *W, const float *bias,
                                                const float *bias2, const float *mask_emb, const int64_t *mask,
-                                               const float *base, int N, int C, int D, int w_lds, int tok) {
+                                               const float *base, int N, int C, int D, int w_lds, int tok, float2 *stats = nullptr, int npad = 0) {
     __shared__ __attribute__((aligned(16))) float xs[EMB_TOK][CMAX];
     extern __shared__ __attribute__((aligned(16))) float4 embed_w_lds[];  // w_lds: (D / ND) x (ND * CMAX / 4 + 1) 16-byte pieces
     const int n_tiles = (N + tok - 1) / tok;  // tok <= EMB_TOK tokens per tile (small launches: smaller tiles, so that every CU gets work)
@@ -356,7 +359,20 @@ __global__ void __launch_bounds__(256) k_embed(float *out, const float *in, cons
                         for (int j = 0; j < ND; ++j) acc[j] = fmaf(xv.w, w[j][c + 3], acc[j]);
                     }
 #pragma unroll
-                    for (int j = 0; j < ND; ++j) out[row + j] = acc[j] + add[u][j];
+                    for (int j = 0; j < ND; ++j) acc[j] = acc[j] + add[u][j];
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) out[row + j] = acc[j];
+                    if constexpr (STATS) {  // (the wave's 64 lanes hold 64 ND consecutive features of ONE token: DQ is a multiple of 64, host-checked)
+                        float s = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) s += acc[j];
+                        const float mean = wave_sum_dpp(s) * (1.0f / (64.0f * ND));
+                        float q = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) q = fmaf(acc[j] - mean, acc[j] - mean, q);
+                        const float m2 = wave_sum_dpp(q);
+                        if ((threadIdx.x & 63) == 0) stats[(size_t)(dq >> 6) * npad + n0 + tkn] = make_float2(mean, m2);
+                    }
                 }
             }
         }
@@ -551,10 +567,10 @@ __global__ void __launch_bounds__(256) k_ln_modulate_v4(u16 *a, const float *h, 
     }
 }
 
-// Per-token LayerNorm statistics from the per-wave partials k_linear2_ws<LNS> leaves beside the residual stream (round 6): parts = D / 32 pairs
-// (mean, sum of squared deviations) over 32 features each, plane-major [part][npad]; combined in part order by the pairwise update of Chan et
+// Per-token LayerNorm statistics from the per-wave partials k_linear2_ws<LNS> leaves beside the residual stream (round 6): parts = D / gsz pairs
+// (mean, sum of squared deviations) over gsz features each (32: k_linear2_ws; 64 ND: k_embed<STATS>), plane-major [part][npad]; combined in part order by the pairwise update of Chan et
 // al. (a fixed order: a token's statistics do not depend on the launch) into (rstd, -mean rstd), eps 1e-6 like k_ln_modulate.
-__global__ void __launch_bounds__(256) k_ln_finalize(float2 *tok, const float2 *parts_in, int parts, int npad, int N) {
+__global__ void __launch_bounds__(256) k_ln_finalize(float2 *tok, const float2 *parts_in, int parts, int npad, int N, float gsz = 32.0f) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     float2 st[16];  // (parts <= 16: hidden <= 512; one pass over the partials, all requests in flight together)
@@ -567,9 +583,9 @@ __global__ void __launch_bounds__(256) k_ln_finalize(float2 *tok, const float2 *
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
         const float d = st[p].x - mean;
-        if (p < parts) q += st[p].y + 32.0f * d * d;
+        if (p < parts) q += st[p].y + gsz * d * d;
     }
-    const float rstd = rsqrtf(q / (float)(32 * parts) + 1e-6f);
+    const float rstd = rsqrtf(q / (gsz * (float)parts) + 1e-6f);
     tok[n] = make_float2(rstd, -mean * rstd);
 }
 
