@@ -549,7 +549,8 @@ def test_committed_traffic_file_reproduces_from_the_committed_pmc_summary(tmp_pa
         assert again == committed, f
         # the decomposition's floors as DESIGN.md section 5 states them: HBM floor above the MFMA floor
         assert committed["step"]["hbm_floor_ms_at_8_tb_s"] > committed["step"]["mfma_floor_ms_at_2_5_pflop_s"] > 0, f
-        for cls in ("linear1", "linear2", "attention", "ln_modulate"):
+        # (a profile of an ln_fuse handle may hold no LayerNorm kernel at all: the statistics come from the embedding and from linear2)
+        for cls in ("linear1", "linear2", "attention") + (() if committed.get("ln_fuse") else ("ln_modulate",)):
             assert committed[cls]["bytes"] > 0 and committed[cls]["avg_us"] > 0, (f, cls)
     assert {"md17_bench", "md17_ref", "nba", "peptide"} <= workloads
 
